@@ -1,0 +1,127 @@
+"""ctypes binding of oracle/libpda_oracle.so (test infrastructure; see package docstring)."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f32p = ctypes.POINTER(ctypes.c_float)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+def lib_path():
+    return os.path.join(_HERE, "libpda_oracle.so")
+
+
+def build(force=False):
+    """Compile the C restatement with gcc (recipe: oracle/Makefile)."""
+    src = os.path.join(_HERE, "pointnet2_oracle.c")
+    so = lib_path()
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "libpda_oracle.so"],
+                              stdout=subprocess.DEVNULL)
+    return so
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(lib_path()):
+            build()
+        _LIB = ctypes.CDLL(lib_path())
+    return _LIB
+
+
+def _f(a, shape=None):
+    assert isinstance(a, np.ndarray) and a.dtype == np.float32 and a.flags.c_contiguous, \
+        "oracle expects C-contiguous float32 numpy arrays"
+    if shape is not None:
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
+    return a.ctypes.data_as(_f32p)
+
+
+def _i(a, shape=None):
+    assert isinstance(a, np.ndarray) and a.dtype == np.int32 and a.flags.c_contiguous, \
+        "oracle expects C-contiguous int32 numpy arrays"
+    if shape is not None:
+        assert tuple(a.shape) == tuple(shape), (a.shape, shape)
+    return a.ctypes.data_as(_i32p)
+
+
+def opt_n_threads(n):
+    return int(_lib().pda_oracle_opt_n_threads(int(n)))
+
+
+def num_threads():
+    return int(_lib().pda_oracle_num_threads())
+
+
+def set_num_threads(n):
+    _lib().pda_oracle_set_num_threads(int(n))
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    return _lib().pda_oracle_ball_query(b, n, m, ctypes.c_float(radius), nsample,
+                                        _f(new_xyz, (b, m, 3)), _f(xyz, (b, n, 3)),
+                                        _i(idx, (b, m, nsample)))
+
+
+def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx):
+    return _lib().pda_oracle_ball_query_dilated(b, n, m, ctypes.c_float(max_radius),
+                                                ctypes.c_float(min_radius), nsample,
+                                                _f(new_xyz, (b, m, 3)), _f(xyz, (b, n, 3)),
+                                                _i(idx, (b, m, nsample)))
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    return _lib().pda_oracle_group_points(b, c, n, npoints, nsample, _f(points, (b, c, n)),
+                                          _i(idx, (b, npoints, nsample)),
+                                          _f(out, (b, c, npoints, nsample)))
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    return _lib().pda_oracle_group_points_grad(b, c, n, npoints, nsample,
+                                               _f(grad_out, (b, c, npoints, nsample)),
+                                               _i(idx, (b, npoints, nsample)),
+                                               _f(grad_points, (b, c, n)))
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    return _lib().pda_oracle_gather_points(b, c, n, npoints, _f(points, (b, c, n)),
+                                           _i(idx, (b, npoints)), _f(out, (b, c, npoints)))
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    return _lib().pda_oracle_gather_points_grad(b, c, n, npoints, _f(grad_out, (b, c, npoints)),
+                                                _i(idx, (b, npoints)),
+                                                _f(grad_points, (b, c, n)))
+
+
+def farthest_point_sampling_wrapper(b, n, m, xyz, temp, idx):
+    return _lib().pda_oracle_furthest_point_sampling(b, n, m, _f(xyz, (b, n, 3)),
+                                                     _f(temp, (b, n)), _i(idx, (b, m)))
+
+
+def furthest_point_sampling_with_dist_wrapper(b, n, m, dist, temp, idx):
+    return _lib().pda_oracle_furthest_point_sampling_with_dist(b, n, m, _f(dist, (b, n, n)),
+                                                               _f(temp, (b, n)),
+                                                               _i(idx, (b, m)))
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _lib().pda_oracle_three_nn(b, n, m, _f(unknown, (b, n, 3)), _f(known, (b, m, 3)),
+                               _f(dist2, (b, n, 3)), _i(idx, (b, n, 3)))
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _lib().pda_oracle_three_interpolate(b, c, m, n, _f(points, (b, c, m)), _i(idx, (b, n, 3)),
+                                        _f(weight, (b, n, 3)), _f(out, (b, c, n)))
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _lib().pda_oracle_three_interpolate_grad(b, c, n, m, _f(grad_out, (b, c, n)),
+                                             _i(idx, (b, n, 3)), _f(weight, (b, n, 3)),
+                                             _f(grad_points, (b, c, m)))
