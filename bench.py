@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- scenes/sec of the PDA-SSD hot path on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one pass of the hot path over one per-GPU batch of synthetic scenes (ONCE,
+16384 points, batch 2 per GPU = BASELINE configs[1]; weak scaling: every rank processes its
+own scenes, no data-path collective for the forward workload).  Inputs are resident in HBM
+before the timed region.  One JSON line is printed by rank 0.
+
+Workloads (--workload):
+  sampling_grouping  the sampling/grouping operators of the PDA-SSD backbone at the ONCE
+                     16384-pt layer shapes: FPS, ball queries, gathers,
+                     groupings -- the operators this repo implements as HIP kernels.
+  backbone           full backbone forward+backward (registered by pdanet_amd.backbone when
+                     present).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+
+# ONCE PDA-SSD layer shapes at N_in = 16384:
+#   (centres M, points N, [(radius, nsample)], feature channels C)
+ONCE16K_LAYERS = [
+    dict(name="L0", M=16384, N=16384, scales=[(0.2, 16), (0.8, 32)], C=1, fps=None),
+    dict(name="L1", M=4096, N=16384, scales=[(0.8, 16), (1.6, 32)], C=64, fps=(16384, 4096)),
+    dict(name="L2", M=2048, N=4096, scales=[(1.6, 16), (4.8, 32)], C=128, fps=None),
+    dict(name="L5", M=1024, N=2048, scales=[(4.8, 16), (8.4, 32), (12.8, 64)], C=256, fps=None),
+]
+
+
+def fps_algorithmic_bytes(n, m):
+    return (m - 1) * n * 20 + m * 4  # BASELINE.md section 2, per scene
+
+
+class SamplingGroupingWorkload:
+    """All sampling/grouping operator calls of one PDA-SSD backbone forward (ONCE-16k)."""
+
+    name = "once16k_b2_sampling_grouping"
+
+    def __init__(self, batch, n_points, device, rank):
+        from pdanet_amd import pointnet2_utils as pu, synth
+        self.pu = pu
+        self.B, self.N = batch, n_points
+        xyz = synth.batch_xyz(batch, n_points, config_id=2 + 10 * rank, dist="L")
+        self.xyz_np = xyz
+        self.xyz = torch.from_numpy(xyz).to(device)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.feats = {L["name"]: torch.randn(batch, L["C"], L["N"], generator=g).to(device)
+                      for L in ONCE16K_LAYERS}
+        self.fps_events = []
+        self.record = False
+
+    def step(self):
+        pu = self.pu
+        xyz = self.xyz
+        out = 0
+        for L in ONCE16K_LAYERS:
+            pts = xyz[:, :L["N"]].contiguous() if L["N"] != xyz.shape[1] else xyz
+            if L["fps"] is not None:
+                if self.record:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                idx = pu.furthest_point_sample(pts, L["M"])
+                if self.record:
+                    e1.record()
+                    self.fps_events.append((e0, e1))
+                new_xyz = pu.gather_operation(pts.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+            else:
+                new_xyz = pts[:, :L["M"]].contiguous()
+            idxs = pu.ball_query_multi([r for r, _ in L["scales"]], [ns for _, ns in L["scales"]], pts, new_xyz)
+            pts_t = pts.transpose(1, 2).contiguous()
+            for idx_s in idxs:
+                gx = pu.grouping_operation(pts_t, idx_s)
+                gf = pu.grouping_operation(self.feats[L["name"]], idx_s)
+                out = out + gx.numel() + gf.numel()
+            xyz = new_xyz if L["name"] != "L5" else xyz
+        return out
+
+    def fps_shape(self):
+        return 16384, 4096
+
+    def cpu_baseline(self, budget_s=20.0):
+        """The same operator sequence through the CPU oracle (kind 'port'), on scene 0."""
+        import oracle
+        nthreads = oracle.num_threads()
+        xyz = np.ascontiguousarray(self.xyz_np[:1])
+        t0 = time.perf_counter()
+        cur = xyz
+        for L in ONCE16K_LAYERS:
+            pts = np.ascontiguousarray(cur[:, :L["N"]])
+            n = pts.shape[1]
+            if L["fps"] is not None:
+                temp = np.full((1, n), 1e10, np.float32)
+                idx = np.zeros((1, L["M"]), np.int32)
+                oracle.farthest_point_sampling_wrapper(1, n, L["M"], pts, temp, idx)
+                new_xyz = np.ascontiguousarray(pts[0][idx[0]][None])
+            else:
+                new_xyz = np.ascontiguousarray(pts[:, :L["M"]])
+            feats = np.zeros((1, L["C"], n), np.float32)
+            pts_t = np.ascontiguousarray(pts.transpose(0, 2, 1))
+            for r, ns in L["scales"]:
+                bq = np.zeros((1, L["M"], ns), np.int32)
+                oracle.ball_query_wrapper(1, n, L["M"], r, ns, new_xyz, pts, bq)
+                gx = np.empty((1, 3, L["M"], ns), np.float32)
+                oracle.group_points_wrapper(1, 3, n, L["M"], ns, pts_t, bq, gx)
+                gf = np.empty((1, L["C"], L["M"], ns), np.float32)
+                oracle.group_points_wrapper(1, L["C"], n, L["M"], ns, feats, bq, gf)
+            cur = new_xyz if L["name"] != "L5" else cur
+        dt = time.perf_counter() - t0
+        return dict(value=1.0 / dt, unit="scenes/s", cores=nthreads, kind="port",
+                    sample="1 scene (scene 0 of the GPU batch), same operator sequence through "
+                           "oracle/libpda_oracle.so (OpenMP, %d threads), %.2f s" % (nthreads, dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="auto")
+    ap.add_argument("--batch", type=int, default=2, help="scenes per GPU (ONCE yaml: 2)")
+    ap.add_argument("--points", type=int, default=16384)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)  # backend "nccl" is RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+
+    workload = args.workload
+    if workload == "auto":
+        try:
+            from pdanet_amd import bench_workloads  # full backbone, when built
+            workload = bench_workloads.DEFAULT
+        except ImportError:
+            workload = "sampling_grouping"
+    if workload == "sampling_grouping":
+        wl = SamplingGroupingWorkload(args.batch, args.points, device, rank)
+    else:
+        from pdanet_amd import bench_workloads
+        wl = bench_workloads.create(workload, args.batch, args.points, device, rank, world)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        wl.step()
+    barrier()
+    wl.record = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    wl.record = False
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # dominant sampling kernel: FPS, timed live with events on the launch stream
+    n, m = wl.fps_shape()
+    fps_ms = [e0.elapsed_time(e1) for e0, e1 in wl.fps_events]
+    fps_avg_s = (sum(fps_ms) / max(1, len(fps_ms))) * 1e-3
+    alg_bytes = fps_algorithmic_bytes(n, m) * args.batch
+    achieved = alg_bytes / fps_avg_s / 1e9 if fps_avg_s > 0 else 0.0
+
+    scenes = args.batch * world * args.steps
+    line = {
+        "metric": "scenes/sec (16384-pt ONCE, PDA-SSD hot path)",
+        "value": scenes / dt,
+        "unit": "scenes/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": getattr(wl, "dtype", "f32"),
+        "data": "synthetic",
+        "config": {"workload": wl.name, "scenes_per_gpu": args.batch, "points_per_scene": args.points,
+                   "parallelism": "dp%d" % world},
+        "roofline": {
+            "kernel": "fps_reg_kernel<16> (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": fps_avg_s * 1e3,
+            "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene) / kernel time; the kernel keeps "
+                    "the scene in registers, so real HBM traffic is the compulsory N*16+m*4 bytes",
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = wl.cpu_baseline()
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,122 @@
+/*
+ * pda_pointnet2.h -- C ABI of libpda_pointnet2.so, the MI355X (gfx950) implementation of
+ * the PDA-SSD point-sampling / grouping hot path.
+ *
+ * Drop-in boundary: these entry points are what a binding of the reference's extension
+ * module `pointnet2_batch_cuda` would call.  The reference binds 14 functions with pybind11
+ * (/root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:12-33); each
+ * declaration below cites the reference wrapper it replaces.  Differences from the
+ * reference wrappers, by design of a C ABI:
+ *   - raw device pointers + sizes instead of at::Tensor; all buffers are caller-allocated,
+ *     contiguous, fp32 / int32, resident on the device that `stream` belongs to;
+ *   - an explicit stream (hipStream_t passed as void*; NULL = the null stream) instead of
+ *     the legacy default stream; every call is asynchronous and captures into hipGraphs
+ *     (no allocation, no synchronisation inside);
+ *   - a status code is returned (PDA_OK == 0) instead of the reference's
+ *     fprintf(stderr)+exit(-1) (e.g. sampling_gpu.cu:248-252); pda_last_error() gives the
+ *     message for the calling thread.  The Python mirror (pdanet_amd/pointnet2_batch_cuda.py)
+ *     raises on non-zero status and returns the reference's own return values (1 / 2 / None).
+ *
+ * Initialisation contracts are the reference's (pointnet2_utils.py:26,95,174,218,246):
+ * FPS `temp` arrives filled with 1e10 and is clobbered; ball-query `idx` arrives zeroed and
+ * rows without any neighbour are left untouched; every `*_grad` output arrives zeroed and is
+ * accumulated into.
+ */
+#ifndef PDA_POINTNET2_H
+#define PDA_POINTNET2_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PDA_OK 0
+#define PDA_ERR_INVALID_ARGUMENT 1 /* null pointer / negative or inconsistent size */
+#define PDA_ERR_LAUNCH 2           /* HIP reported a launch error */
+#define PDA_ERR_UNSUPPORTED 3      /* shape outside what the kernels were built for */
+
+typedef void *pda_stream_t; /* hipStream_t */
+
+/* ABI version of this header (bumped on any signature change). */
+#define PDA_POINTNET2_ABI_VERSION 3
+int pda_abi_version(void);
+/* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
+const char *pda_last_error(void);
+/* 1 if the library was compiled with the nvcc-style contraction fma(dz,dz,fma(dy,dy,dx*dx))
+ * of the squared distance (default), 0 for the uncontracted form.  Must match the oracle. */
+int pda_fp_contract_mode(void);
+/* Block size the reference launcher would choose for `work_size` (cuda_utils.h:10-14);
+ * it fixes the FPS tie-breaking and is exported so hosts/tests can state it. */
+int pda_opt_n_threads(int work_size);
+
+/* ---- furthest point sampling ------------------------------------------------------- */
+/* replaces farthest_point_sampling_wrapper (sampling.cpp:34-43, pointnet2_api.cpp:27;
+ * kernel sampling_gpu.cu:93-253).  xyz (b,n,3), temp (b,n) pre-filled 1e10 (clobbered:
+ * holds the final min squared distances on return), idx (b,m).  Index-exact including the
+ * reference's shared-memory-tree tie-breaking. */
+int pda_furthest_point_sampling(const float *xyz, float *temp, int32_t *idx, int b, int n, int m,
+                                pda_stream_t stream);
+/* replaces furthest_point_sampling_with_dist_wrapper (sampling.cpp:46-56,
+ * pointnet2_api.cpp:28; kernel sampling_gpu.cu:256-416).  dist (b,n,n). */
+int pda_furthest_point_sampling_with_dist(const float *dist, float *temp, int32_t *idx, int b,
+                                          int n, int m, pda_stream_t stream);
+
+/* ---- gather ------------------------------------------------------------------------ */
+/* replaces gather_points_wrapper_fast (sampling.cpp:11-19; kernel sampling_gpu.cu:8-44):
+ * out[b,c,j] = points[b,c,idx[b,j]];  points (b,c,n), idx (b,m), out (b,c,m). */
+int pda_gather_points(const float *points, const int32_t *idx, float *out, int b, int c, int n,
+                      int m, pda_stream_t stream);
+/* replaces gather_points_grad_wrapper_fast (sampling.cpp:22-31; kernel sampling_gpu.cu:46-83):
+ * grad_points[b,c,idx[b,j]] += grad_out[b,c,j];  grad_points (b,c,n) pre-zeroed. */
+int pda_gather_points_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b,
+                           int c, int n, int m, pda_stream_t stream);
+
+/* ---- ball query -------------------------------------------------------------------- */
+/* replaces ball_query_wrapper_fast (ball_query.cpp:32-42; kernel ball_query_gpu.cu:9-67).
+ * new_xyz (b,m,3), xyz (b,n,3), idx (b,m,nsample) pre-zeroed.  First `nsample` points in
+ * ascending index with d2 < radius*radius; the first hit pre-fills the row. */
+int pda_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
+                   float radius, int nsample, pda_stream_t stream);
+/* replaces ball_query_dilated_wrapper_fast (ball_query.cpp:45-56; kernel
+ * ball_query_gpu.cu:70-139), including the d2==0 double append. */
+int pda_ball_query_dilated(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n,
+                           int m, float max_radius, float min_radius, int nsample,
+                           pda_stream_t stream);
+/* MI355X extension (no reference counterpart): up to 3 radii over the SAME centres and
+ * points in one pass -- the multi-scale groupers call ball_query once per scale
+ * (pointnet2_modules.py:1657).  idx[i] is (b,m,nsamples[i]); results are identical to
+ * `nr` separate pda_ball_query calls. */
+int pda_ball_query_multi(const float *new_xyz, const float *xyz, int32_t *const *idx, int b, int n,
+                         int m, int nr, const float *radii, const int32_t *nsamples,
+                         pda_stream_t stream);
+
+/* ---- grouping ---------------------------------------------------------------------- */
+/* replaces group_points_wrapper_fast (group_points.cpp:30-41; kernel
+ * group_points_gpu.cu:53-92): out[b,c,p,s] = points[b,c,idx[b,p,s]]. */
+int pda_group_points(const float *points, const int32_t *idx, float *out, int b, int c, int n,
+                     int npoints, int nsample, pda_stream_t stream);
+/* replaces group_points_grad_wrapper_fast (group_points.cpp:18-28; kernel
+ * group_points_gpu.cu:14-50): grad_points[b,c,idx[b,p,s]] += grad_out[b,c,p,s]. */
+int pda_group_points_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b,
+                          int c, int n, int npoints, int nsample, pda_stream_t stream);
+
+/* ---- three-NN + interpolation ------------------------------------------------------ */
+/* replaces three_nn_wrapper_fast (interpolate.cpp:21-30; kernel interpolate_gpu.cu:16-81).
+ * unknown (b,n,3), known (b,m,3) -> dist2 (b,n,3) squared distances, idx (b,n,3). */
+int pda_three_nn(const float *unknown, const float *known, float *dist2, int32_t *idx, int b,
+                 int n, int m, pda_stream_t stream);
+/* replaces three_interpolate_wrapper_fast (interpolate.cpp:32-44; kernel
+ * interpolate_gpu.cu:84-124): out[b,c,j] = sum_t weight[b,j,t] * points[b,c,idx[b,j,t]]. */
+int pda_three_interpolate(const float *points, const int32_t *idx, const float *weight,
+                          float *out, int b, int c, int m, int n, pda_stream_t stream);
+/* replaces three_interpolate_grad_wrapper_fast (interpolate.cpp:46-58; kernel
+ * interpolate_gpu.cu:127-168): grad_points (b,c,m) pre-zeroed. */
+int pda_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight,
+                               float *grad_points, int b, int c, int n, int m,
+                               pda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PDA_POINTNET2_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of the C ABI declared in include/pda_pointnet2.h.
+
+The library is the product: if it is missing or a symbol is absent this module raises at
+import of the first op -- there is no fallback path.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpda_pointnet2.so")
+ABI_VERSION = 3
+
+_vp = ctypes.c_void_p
+_i = ctypes.c_int
+_f = ctypes.c_float
+
+# name -> argtypes, in the order of include/pda_pointnet2.h
+SIGNATURES = {
+    "pda_furthest_point_sampling": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "pda_furthest_point_sampling_with_dist": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "pda_gather_points": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_gather_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
+    "pda_ball_query_dilated": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
+    "pda_ball_query_multi": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i,
+                             ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int32), _vp],
+    "pda_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_group_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "pda_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+}
+INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
+
+_LIB = None
+
+
+class PdaError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpda_pointnet2.so (after torch, so both share one HIP runtime)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (loads libamdhip64 first; our NEEDED soname resolves to it)
+    if not os.path.exists(LIB_PATH):
+        raise PdaError(
+            "%s not found: build it with `python -m pdanet_amd.build` (hipcc, gfx950). "
+            "pdanet_amd has no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
+        fn.argtypes = argtypes
+        fn.restype = _i
+    lib.pda_abi_version.restype = _i
+    lib.pda_last_error.restype = ctypes.c_char_p
+    lib.pda_fp_contract_mode.restype = _i
+    lib.pda_opt_n_threads.argtypes = [_i]
+    lib.pda_opt_n_threads.restype = _i
+    if lib.pda_abi_version() != ABI_VERSION:
+        raise PdaError("libpda_pointnet2.so ABI %d != binding ABI %d: rebuild"
+                       % (lib.pda_abi_version(), ABI_VERSION))
+    _LIB = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().pda_last_error().decode("utf-8", "replace")
+        raise PdaError("%s failed with status %d: %s" % (what, status, msg))

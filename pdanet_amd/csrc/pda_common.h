@@ -1,0 +1,123 @@
+// pda_common.h -- shared host/device helpers for libpda_pointnet2.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/pda_pointnet2.h"
+
+#ifndef PDA_FP_CONTRACT
+#define PDA_FP_CONTRACT 1  // 1: fma(dz,dz,fma(dy,dy,dx*dx)) (nvcc -fmad=true); 0: uncontracted
+#endif
+
+#define PDA_API extern "C" __attribute__((visibility("default")))
+#define PDA_WAVE 64
+
+namespace pda {
+
+// ---- host-side status plumbing ---------------------------------------------------------
+void set_error(const char* fmt, ...);
+
+
+#define PDA_REQUIRE(cond, ...)                                      \
+    do {                                                            \
+        if (!(cond)) {                                              \
+            ::pda::set_error(__VA_ARGS__);                          \
+            return PDA_ERR_INVALID_ARGUMENT;                        \
+        }                                                           \
+    } while (0)
+
+inline int check_launch(const char* what) {
+    hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        set_error("%s: HIP launch failed: %s", what, hipGetErrorString(err));
+        return PDA_ERR_LAUNCH;
+    }
+    return PDA_OK;
+}
+
+inline int divup(int a, int b) { return (a + b - 1) / b; }
+inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// ---- device helpers --------------------------------------------------------------------
+// Squared distance (a - b), the one expression every query kernel shares
+// (ball_query_gpu.cu:33, interpolate_gpu.cu:43, sampling_gpu.cu:133).  The file is built
+// with -ffp-contract=off, so the only contraction is the one written here.
+__device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx, float by,
+                                         float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+#if PDA_FP_CONTRACT
+    return __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));
+#else
+    return (dx * dx + dy * dy) + dz * dz;
+#endif
+}
+
+// wave-uniform wave index inside the workgroup, provably uniform to the compiler
+__device__ __forceinline__ int wave_id() {
+    return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+}
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+// Read-only, wave-uniform streams (the point cloud every lane tests against) are read
+// through the CONSTANT address space: with a wave-uniform address the backend then emits
+// scalar loads (s_load_dwordxN into SGPRs) instead of 64-lane vector loads.  Only valid for
+// buffers no kernel in flight writes (xyz / known / new_xyz inputs).
+typedef const float __attribute__((address_space(4))) * cfloat_ptr;
+__device__ __forceinline__ cfloat_ptr as_constant(const float* p) {
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wold-style-cast"
+    return (cfloat_ptr)p;
+#pragma clang diagnostic pop
+}
+
+// Forces a pointer the program knows to be wave-uniform into SGPRs (two v_readfirstlane);
+// divergence analysis loses uniformity across PHIs that join divergent control flow.
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const uint64_t v = (uint64_t)p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+    const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return (T*)(((uint64_t)hi << 32) | lo);
+}
+
+// Wave-wide reductions of idempotent ops with the DPP modifier fused into the ALU op
+// (gfx9 DPP: row_shr:n inside rows of 16 lanes, then row_bcast:15 / row_bcast:31 across
+// rows).  A lane whose DPP source is out of range keeps its own value.  `s_nop 1` covers
+// the 2-wait-state VALU-write -> DPP-read hazard, which hipcc does not pad inside asm.
+// Result: valid in lane 63, returned wave-uniform through readlane.
+#define PDA_DPP_REDUCE64(OP)                                                   \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"  \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"  \
+    "s_nop 1"
+// Same over the first 16 lanes only (row 0); result valid in lane 15.
+#define PDA_DPP_REDUCE16(OP)                                                   \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1"
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+    asm volatile(PDA_DPP_REDUCE64("v_max_f32_dpp") : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    asm volatile(PDA_DPP_REDUCE64("v_min_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+__device__ __forceinline__ float row0_max_f32(float v) {
+    asm volatile(PDA_DPP_REDUCE16("v_max_f32_dpp") : "+v"(v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 15));
+}
+__device__ __forceinline__ uint32_t row0_min_u32(uint32_t v) {
+    asm volatile(PDA_DPP_REDUCE16("v_min_u32_dpp") : "+v"(v));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 15);
+}
+
+}  // namespace pda

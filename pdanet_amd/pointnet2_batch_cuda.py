@@ -1,0 +1,148 @@
+"""Mirror of the reference's extension module ``pointnet2_batch_cuda``.
+
+Same function names and positional signatures as the pybind module defined in
+/root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:12-33, so the
+reference's ``pointnet2_utils.py`` could do ``from pdanet_amd import pointnet2_batch_cuda as
+pointnet2`` unchanged.  Each wrapper validates like the reference's CHECK_INPUT
+(ball_query.cpp:17-29: CUDA tensor + contiguous), launches the HIP kernel on torch's CURRENT
+stream through the C ABI (include/pda_pointnet2.h) and returns what the reference returns
+(1, 2 for the with-dist FPS, None for the interpolate trio).  Where the reference prints and
+calls exit(-1), this raises.  ``ellipsoid_query`` / ``chamfer_*`` are not on the PDA-SSD path
+ and are not provided.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def _chk(t, name, dtype):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA(HIP) tensor -- there is no CPU path" % name)
+    if not t.is_contiguous():
+        raise RuntimeError("%s must be contiguous" % name)
+    if t.dtype != dtype:
+        raise RuntimeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _numel_ok(t, n, name):
+    if t.numel() < n:
+        raise RuntimeError("%s has %d elements, the sizes passed need %d" % (name, t.numel(), n))
+
+
+def _stream(t):
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def _call(fn_name, tensor, *args):
+    lib = _lib.load()
+    with torch.cuda.device(tensor.device):
+        st = getattr(lib, fn_name)(*args, _stream(tensor))
+    _lib.check(st, fn_name)
+
+
+F32, I32 = torch.float32, torch.int32
+
+
+def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
+    _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(xyz, b * n * 3, "xyz")
+    _numel_ok(idx, b * m * nsample, "idx")
+    _call("pda_ball_query", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32),
+          _chk(idx, "idx", I32), b, n, m, float(radius), nsample)
+    return 1
+
+
+def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx):
+    _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(xyz, b * n * 3, "xyz")
+    _numel_ok(idx, b * m * nsample, "idx")
+    _call("pda_ball_query_dilated", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32),
+          _chk(idx, "idx", I32), b, n, m, float(max_radius), float(min_radius), nsample)
+    return 1
+
+
+def ball_query_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
+    """MI355X extension: several radii over the same centres/points in one pass."""
+    nr = len(radii)
+    assert nr == len(nsamples) == len(idxs)
+    _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(xyz, b * n * 3, "xyz")
+    ptrs = (ctypes.c_void_p * nr)()
+    for i, (t, ns) in enumerate(zip(idxs, nsamples)):
+        _numel_ok(t, b * m * ns, "idx[%d]" % i)
+        ptrs[i] = _chk(t, "idx[%d]" % i, I32)
+    r = (ctypes.c_float * nr)(*[float(x) for x in radii])
+    s = (ctypes.c_int32 * nr)(*[int(x) for x in nsamples])
+    _call("pda_ball_query_multi", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32),
+          ptrs, b, n, m, nr, r, s)
+    return 1
+
+
+def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
+    _numel_ok(points, b * c * n, "points"); _numel_ok(idx, b * npoints * nsample, "idx")
+    _numel_ok(out, b * c * npoints * nsample, "out")
+    _call("pda_group_points", points, _chk(points, "points", F32), _chk(idx, "idx", I32),
+          _chk(out, "out", F32), b, c, n, npoints, nsample)
+    return 1
+
+
+def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_points):
+    _numel_ok(grad_out, b * c * npoints * nsample, "grad_out")
+    _numel_ok(idx, b * npoints * nsample, "idx"); _numel_ok(grad_points, b * c * n, "grad_points")
+    _call("pda_group_points_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(idx, "idx", I32),
+          _chk(grad_points, "grad_points", F32), b, c, n, npoints, nsample)
+    return 1
+
+
+def gather_points_wrapper(b, c, n, npoints, points, idx, out):
+    _numel_ok(points, b * c * n, "points"); _numel_ok(idx, b * npoints, "idx")
+    _numel_ok(out, b * c * npoints, "out")
+    _call("pda_gather_points", points, _chk(points, "points", F32), _chk(idx, "idx", I32),
+          _chk(out, "out", F32), b, c, n, npoints)
+    return 1
+
+
+def gather_points_grad_wrapper(b, c, n, npoints, grad_out, idx, grad_points):
+    _numel_ok(grad_out, b * c * npoints, "grad_out"); _numel_ok(idx, b * npoints, "idx")
+    _numel_ok(grad_points, b * c * n, "grad_points")
+    _call("pda_gather_points_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(idx, "idx", I32),
+          _chk(grad_points, "grad_points", F32), b, c, n, npoints)
+    return 1
+
+
+def farthest_point_sampling_wrapper(b, n, m, xyz, temp, idx):
+    _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(temp, b * n, "temp"); _numel_ok(idx, b * m, "idx")
+    _call("pda_furthest_point_sampling", xyz, _chk(xyz, "xyz", F32), _chk(temp, "temp", F32),
+          _chk(idx, "idx", I32), b, n, m)
+    return 1
+
+
+def furthest_point_sampling_with_dist_wrapper(b, n, m, dist, temp, idx):
+    _numel_ok(dist, b * n * n, "dist"); _numel_ok(temp, b * n, "temp"); _numel_ok(idx, b * m, "idx")
+    _call("pda_furthest_point_sampling_with_dist", dist, _chk(dist, "dist", F32),
+          _chk(temp, "temp", F32), _chk(idx, "idx", I32), b, n, m)
+    return 2  # sampling.cpp:55
+
+
+def three_nn_wrapper(b, n, m, unknown, known, dist2, idx):
+    _numel_ok(unknown, b * n * 3, "unknown"); _numel_ok(known, b * m * 3, "known")
+    _numel_ok(dist2, b * n * 3, "dist2"); _numel_ok(idx, b * n * 3, "idx")
+    _call("pda_three_nn", unknown, _chk(unknown, "unknown", F32), _chk(known, "known", F32),
+          _chk(dist2, "dist2", F32), _chk(idx, "idx", I32), b, n, m)
+
+
+def three_interpolate_wrapper(b, c, m, n, points, idx, weight, out):
+    _numel_ok(points, b * c * m, "points"); _numel_ok(idx, b * n * 3, "idx")
+    _numel_ok(weight, b * n * 3, "weight"); _numel_ok(out, b * c * n, "out")
+    _call("pda_three_interpolate", points, _chk(points, "points", F32), _chk(idx, "idx", I32),
+          _chk(weight, "weight", F32), _chk(out, "out", F32), b, c, m, n)
+
+
+def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_points):
+    _numel_ok(grad_out, b * c * n, "grad_out"); _numel_ok(idx, b * n * 3, "idx")
+    _numel_ok(weight, b * n * 3, "weight"); _numel_ok(grad_points, b * c * m, "grad_points")
+    _call("pda_three_interpolate_grad", grad_out, _chk(grad_out, "grad_out", F32),
+          _chk(idx, "idx", I32), _chk(weight, "weight", F32),
+          _chk(grad_points, "grad_points", F32), b, c, n, m)

@@ -1,0 +1,363 @@
+"""Mirror of the reference's ``pointnet2_batch/pointnet2_utils.py`` operator API.
+
+Same public names, argument order, allocation/initialisation contracts and gradients as
+/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_utils.py (cited per class);
+the kernels underneath are the hand-written gfx950 ones reached through the C ABI
+(``pointnet2_batch_cuda`` mirror).  Differences that are deliberate:
+  * outputs are allocated with ``torch.empty(..., device=input.device)`` and kernels run on
+    the current stream (the reference uses ``torch.cuda.IntTensor(...)`` + the null stream),
+    so the ops work under side streams and hipGraph capture;
+  * the grouper modules use one multi-radius ball query when asked for several scales.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from . import pointnet2_batch_cuda as pointnet2
+
+
+class FarthestPointSampling(Function):
+    """pointnet2_utils.py:10-33.  xyz (B,N,3) -> idx (B,npoint) int32; temp pre-filled 1e10."""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.farthest_point_sampling_wrapper(B, N, npoint, xyz, temp, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+farthest_point_sample = furthest_point_sample = FarthestPointSampling.apply
+
+
+class FurthestPointSamplingWithDist(Function):
+    """pointnet2_utils.py:39-62.  dist matrix (B,N,N) -> idx (B,npoint)."""
+
+    @staticmethod
+    def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        output = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
+        temp = torch.full((B, N), 1e10, dtype=torch.float32, device=xyz.device)
+        pointnet2.furthest_point_sampling_with_dist_wrapper(B, N, npoint, xyz, temp, output)
+        ctx.mark_non_differentiable(output)
+        return output
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None
+
+
+furthest_point_sample_with_dist = FurthestPointSamplingWithDist.apply
+
+
+class GatherOperation(Function):
+    """pointnet2_utils.py:67-98.  features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, npoint = idx.size()
+        _, C, N = features.size()
+        output = torch.empty((B, C, npoint), dtype=torch.float32, device=features.device)
+        pointnet2.gather_points_wrapper(B, C, N, npoint, features, idx, output)
+        ctx.for_backwards = (idx, C, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, C, N = ctx.for_backwards
+        B, npoint = idx.size()
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        pointnet2.gather_points_grad_wrapper(B, C, N, npoint, grad_out_data, idx, grad_features)
+        return grad_features, None
+
+
+gather_operation = GatherOperation.apply
+
+
+class ThreeNN(Function):
+    """pointnet2_utils.py:104-130.  Returns (sqrt(dist2), idx), both (B,N,3)."""
+
+    @staticmethod
+    def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        assert unknown.is_contiguous()
+        assert known.is_contiguous()
+        B, N, _ = unknown.size()
+        m = known.size(1)
+        dist2 = torch.empty((B, N, 3), dtype=torch.float32, device=unknown.device)
+        idx = torch.empty((B, N, 3), dtype=torch.int32, device=unknown.device)
+        pointnet2.three_nn_wrapper(B, N, m, unknown, known, dist2, idx)
+        ctx.mark_non_differentiable(idx)
+        return torch.sqrt(dist2), idx
+
+    @staticmethod
+    def backward(ctx, a=None, b=None):
+        return None, None
+
+
+three_nn = ThreeNN.apply
+
+
+class ThreeInterpolate(Function):
+    """pointnet2_utils.py:136-178.  features (B,C,M), idx/weight (B,n,3) -> (B,C,n)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        assert weight.is_contiguous()
+        B, c, m = features.size()
+        n = idx.size(1)
+        ctx.three_interpolate_for_backward = (idx, weight, m)
+        output = torch.empty((B, c, n), dtype=torch.float32, device=features.device)
+        pointnet2.three_interpolate_wrapper(B, c, m, n, features, idx, weight, output)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, weight, m = ctx.three_interpolate_for_backward
+        B, c, n = grad_out.size()
+        grad_features = torch.zeros((B, c, m), dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        pointnet2.three_interpolate_grad_wrapper(B, c, n, m, grad_out_data, idx, weight, grad_features)
+        return grad_features, None, None
+
+
+three_interpolate = ThreeInterpolate.apply
+
+
+class GroupingOperation(Function):
+    """pointnet2_utils.py:184-222.  features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
+
+    @staticmethod
+    def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert features.is_contiguous()
+        assert idx.is_contiguous()
+        B, nfeatures, nsample = idx.size()
+        _, C, N = features.size()
+        output = torch.empty((B, C, nfeatures, nsample), dtype=torch.float32, device=features.device)
+        pointnet2.group_points_wrapper(B, C, N, nfeatures, nsample, features, idx, output)
+        ctx.for_backwards = (idx, N)
+        return output
+
+    @staticmethod
+    def backward(ctx, grad_out: torch.Tensor):
+        idx, N = ctx.for_backwards
+        B, C, npoint, nsample = grad_out.size()
+        grad_features = torch.zeros((B, C, N), dtype=torch.float32, device=grad_out.device)
+        grad_out_data = grad_out.detach().contiguous()
+        pointnet2.group_points_grad_wrapper(B, C, N, npoint, nsample, grad_out_data, idx, grad_features)
+        return grad_features, None
+
+
+grouping_operation = GroupingOperation.apply
+
+
+class BallQuery(Function):
+    """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
+
+    @staticmethod
+    def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
+        assert new_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_wrapper(B, N, npoint, radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None
+
+
+ball_query = BallQuery.apply
+
+
+class BallQueryDilated(Function):
+    """pointnet2_utils.py:258-284."""
+
+    @staticmethod
+    def forward(ctx, max_radius: float, min_radius: float, nsample: int, xyz: torch.Tensor,
+                new_xyz: torch.Tensor) -> torch.Tensor:
+        assert new_xyz.is_contiguous()
+        assert xyz.is_contiguous()
+        B, N, _ = xyz.size()
+        npoint = new_xyz.size(1)
+        idx = torch.zeros((B, npoint, nsample), dtype=torch.int32, device=xyz.device)
+        pointnet2.ball_query_dilated_wrapper(B, N, npoint, max_radius, min_radius, nsample, new_xyz, xyz, idx)
+        ctx.mark_non_differentiable(idx)
+        return idx
+
+    @staticmethod
+    def backward(ctx, a=None):
+        return None, None, None, None, None
+
+
+ball_query_dilated = BallQueryDilated.apply
+
+
+def ball_query_multi(radii: List[float], nsamples: List[int], xyz: torch.Tensor,
+                     new_xyz: torch.Tensor) -> List[torch.Tensor]:
+    """MI355X extension: the multi-scale groupers' ball queries (one per scale over the same
+    centres, pointnet2_modules.py:1657) in one pass over the points.  Results are identical to
+    ``[ball_query(r, ns, xyz, new_xyz) for r, ns in zip(radii, nsamples)]``."""
+    assert new_xyz.is_contiguous() and xyz.is_contiguous()
+    B, N, _ = xyz.size()
+    npoint = new_xyz.size(1)
+    out: List[torch.Tensor] = []
+    with torch.no_grad():
+        for start in range(0, len(radii), 3):
+            rs, nss = radii[start:start + 3], nsamples[start:start + 3]
+            idxs = [torch.zeros((B, npoint, ns), dtype=torch.int32, device=xyz.device) for ns in nss]
+            pointnet2.ball_query_multi(B, N, npoint, rs, nss, new_xyz, xyz, idxs)
+            out.extend(idxs)
+    return out
+
+
+class QueryAndGroup(nn.Module):
+    """pointnet2_utils.py:671-704: ball query, group xyz (centre-subtracted, :692) and
+    features, concatenate -> (B, 3 + C, npoint, nsample)."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None,
+                idx: torch.Tensor = None) -> torch.Tensor:
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features
+
+
+class QueryDilatedAndGroup(nn.Module):
+    """pointnet2_utils.py:706-741.  NB the reference passes (radius_in, radius_out) into
+    ball_query_dilated's (max_radius, min_radius) slots (:726); kept as is."""
+
+    def __init__(self, radius_in: float, radius_out: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius_in, self.radius_out, self.nsample, self.use_xyz = radius_in, radius_out, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        idx = ball_query_dilated(self.radius_in, self.radius_out, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)
+        grouped_xyz = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features
+
+
+class QueryAndGroup_alone_grouped_density(nn.Module):
+    """pointnet2_utils.py:618-668: like the directional grouper without the direction channels:
+    cat [xyz(3, absolute), density(1), features(C)]."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None,
+                idx: torch.Tensor = None) -> torch.Tensor:
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)
+        distances = torch.norm(grouped_xyz.permute(0, 2, 3, 1).contiguous() - new_xyz.unsqueeze(2), dim=-1)
+        density = torch.exp(-distances ** 2 / (2 * self.radius ** 2)) / (2.5 * self.radius)
+        density = density.unsqueeze(1)
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, density, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features
+
+
+class QueryAndGroup_alone_grouped_density_directional(nn.Module):
+    """The PDA-layer grouper, pointnet2_utils.py:557-614.  Output channel order (:607):
+    [xyz(3, ABSOLUTE coordinates: the centre subtraction is commented out at :602),
+     gaussian density exp(-|d|^2 / (2 r^2)) / (2.5 r) (:594-597),
+     direction (grouped - centre) / r (:599-600),
+     features(C)]  -> (B, 3 + 1 + 3 + C, npoint, nsample)."""
+
+    def __init__(self, radius: float, nsample: int, use_xyz: bool = True):
+        super().__init__()
+        self.radius, self.nsample, self.use_xyz = radius, nsample, use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None,
+                idx: torch.Tensor = None) -> torch.Tensor:
+        if idx is None:
+            idx = ball_query(self.radius, self.nsample, xyz, new_xyz)
+        xyz_trans = xyz.transpose(1, 2).contiguous()
+        grouped_xyz = grouping_operation(xyz_trans, idx)  # (B, 3, npoint, nsample)
+        distances = torch.norm(grouped_xyz.permute(0, 2, 3, 1).contiguous() - new_xyz.unsqueeze(2), dim=-1)
+        density = torch.exp(-distances ** 2 / (2 * self.radius ** 2)) / (2.5 * self.radius)
+        density = density.unsqueeze(1)  # (B, 1, npoint, nsample)
+        directional_vectors = grouped_xyz - new_xyz.transpose(1, 2).unsqueeze(-1)
+        directional_vectors = directional_vectors / self.radius
+        if features is not None:
+            grouped_features = grouping_operation(features, idx)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, density, directional_vectors, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            assert self.use_xyz, "Cannot have not features and not use xyz as a feature!"
+            new_features = grouped_xyz
+        return new_features
+
+
+class GroupAll(nn.Module):
+    """pointnet2_utils.py:743-766."""
+
+    def __init__(self, use_xyz: bool = True):
+        super().__init__()
+        self.use_xyz = use_xyz
+
+    def forward(self, xyz: torch.Tensor, new_xyz: torch.Tensor, features: torch.Tensor = None):
+        grouped_xyz = xyz.transpose(1, 2).unsqueeze(2)
+        if features is not None:
+            grouped_features = features.unsqueeze(2)
+            if self.use_xyz:
+                new_features = torch.cat([grouped_xyz, grouped_features], dim=1)
+            else:
+                new_features = grouped_features
+        else:
+            new_features = grouped_xyz
+        return new_features

@@ -1,0 +1,75 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds, loads and exports
+every symbol include/pda_pointnet2.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pdanet_amd import build, _lib
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pda_pointnet2.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pda_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 16
+    for n in names:
+        assert hasattr(lib, n), "libpda_pointnet2.so does not export %s" % n
+
+
+def test_binding_covers_header():
+    from pdanet_amd import _lib
+    assert sorted(list(_lib.SIGNATURES) + _lib.INFO_SYMBOLS) == _declared_symbols()
+
+
+def test_info_entry_points(lib, oracle):
+    assert lib.pda_abi_version() == 3
+    assert lib.pda_fp_contract_mode() == 1
+    for n in [1, 2, 3, 7, 8, 100, 1000, 1023, 1024, 4096, 16384, 60000, 65536]:
+        assert lib.pda_opt_n_threads(n) == oracle.opt_n_threads(n)
+
+
+def test_argument_validation_without_gpu(lib):
+    # invalid sizes are rejected before any HIP call, so this runs on a CPU-only box
+    st = lib.pda_ball_query(None, None, None, 1, 8, 8, ctypes.c_float(1.0), 0, None)
+    assert st == 1 and b"nsample" in lib.pda_last_error()
+    st = lib.pda_furthest_point_sampling(None, None, None, -1, 8, 8, None)
+    assert st == 1
+    st = lib.pda_group_points(None, None, None, 1, 1, 1, -1, 1, None)
+    assert st == 1
+    # empty problems are PDA_OK and touch nothing
+    assert lib.pda_ball_query(None, None, None, 0, 8, 8, ctypes.c_float(1.0), 4, None) == 0
+    assert lib.pda_furthest_point_sampling(None, None, None, 2, 8, 0, None) == 0
+    assert lib.pda_group_points(None, None, None, 2, 0, 4, 4, 4, None) == 0
+
+
+def test_mirror_module_matches_reference_names():
+    # the 11 reference extension entry points on this path (pointnet2_api.cpp:12-33)
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    for name in ["ball_query_wrapper", "ball_query_dilated_wrapper", "group_points_wrapper",
+                 "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
+                 "farthest_point_sampling_wrapper", "furthest_point_sampling_with_dist_wrapper",
+                 "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+        assert callable(getattr(ext, name))
+
+
+def test_ops_refuse_cpu_tensors():
+    import torch
+    from pdanet_amd import pointnet2_utils as pu
+    xyz = torch.zeros(1, 16, 3)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pu.ball_query(1.0, 4, xyz, xyz)
+    with pytest.raises(RuntimeError, match="no CPU path"):
+        pu.furthest_point_sample(xyz, 4)
