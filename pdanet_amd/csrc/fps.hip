@@ -17,6 +17,10 @@
 //     (max min-dist, then min (bitreverse(k mod bs), k / bs)), bs = the reference's block size
 //     (pinned by tests/test_oracle_known_answers.py);
 //   * the winner's coordinates are fetched with a scalar load (wave-uniform address).
+//   Measured dead ends (MI355X, 16384->4096, B=2; profiles/r01_fps_variants.txt): packing two
+//   points per v_pk_{add,mul,fma}_f32 is 13 % SLOWER (5.40 vs 4.79 ms: packed f32 issues at half
+//   rate and costs extra moves), 512 lanes x 32 points/lane 22-36 % slower (fewer waves to
+//   cover the reduction latency).
 // fps_stream_kernel<WITH_DIST> (any N; also the (B,N,N) distance-matrix variant)
 //   * same reduction, but xyz (or the dist row) and temp stream from L2/HBM each iteration.
 // Algorithmic bytes: (m-1)*N*20 + m*4 per scene; compulsory bytes N*16 + m*4.
