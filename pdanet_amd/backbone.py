@@ -1,0 +1,149 @@
+"""IASSD_Backbone restated: builds the six SA layers of PDA-SSD from the (unchanged) yaml and
+runs them (/root/reference/pcdet/models/backbones_3d/IASSD_backbone.py:9-240).
+
+Same constructor signature, forward(batch_dict) contract, output keys and state-dict keys
+(`SA_modules.<k>....`).  Layer classes are chosen by index exactly as the reference does
+(:62-94): k in {1,2,3} -> the PDA layer, k = 0 or k > 4 -> the vanilla SA layer, and the
+`Vote_Layer` entry -> Vote_layer.
+
+Differences (results unchanged): the per-scene point count is taken from the tensor shape
+(the reference counts `batch_idx == b` per scene and asserts min == max, a device->host sync
+per forward, :131-137), and the D-FPS of layer k+1 can be launched on a side stream when it
+depends only on coordinates (see `prefetch_fps`).
+"""
+import torch
+import torch.nn as nn
+
+from . import pointnet2_modules
+
+
+class IASSD_Backbone(nn.Module):
+    def __init__(self, model_cfg, num_class, input_channels, **kwargs):
+        super().__init__()
+        self.model_cfg = model_cfg
+        self.num_class = num_class
+        self.SA_modules = nn.ModuleList()
+        channel_in = input_channels - 3
+        channel_out_list = [channel_in]
+        self.num_points_each_layer = []
+
+        sa_config = self.model_cfg.SA_CONFIG
+        self.layer_types = sa_config.LAYER_TYPE
+        self.ctr_idx_list = sa_config.CTR_INDEX
+        self.layer_inputs = sa_config.LAYER_INPUT
+        self.aggregation_mlps = sa_config.get('AGGREGATION_MLPS', None)
+        self.confidence_mlps = sa_config.get('CONFIDENCE_MLPS', None)
+        self.max_translate_range = sa_config.get('MAX_TRANSLATE_RANGE', None)
+
+        for k in range(len(sa_config.NSAMPLE_LIST)):
+            if isinstance(self.layer_inputs[k], list):
+                channel_in = channel_out_list[self.layer_inputs[k][-1]]
+            else:
+                channel_in = channel_out_list[self.layer_inputs[k]]
+
+            if self.layer_types[k] == 'SA_Layer':
+                mlps = [[channel_in] + list(spec) for spec in sa_config.MLPS[k]]
+                channel_out = sum(spec[-1] for spec in mlps)
+                aggregation_mlp = None
+                if self.aggregation_mlps and self.aggregation_mlps[k]:
+                    aggregation_mlp = list(self.aggregation_mlps[k])
+                    channel_out = aggregation_mlp[-1]
+                confidence_mlp = None
+                if self.confidence_mlps and self.confidence_mlps[k]:
+                    confidence_mlp = list(self.confidence_mlps[k])
+                cls = (pointnet2_modules.PointnetSAModuleMSG_WithSampling if (k < 1 or k > 4)
+                       else pointnet2_modules.PointnetSAModuleMSG_WithSampling_Ellipsoid)
+                self.SA_modules.append(cls(
+                    npoint_list=sa_config.NPOINT_LIST[k],
+                    sample_range_list=sa_config.SAMPLE_RANGE_LIST[k],
+                    sample_type_list=sa_config.SAMPLE_METHOD_LIST[k],
+                    radii=sa_config.RADIUS_LIST[k],
+                    nsamples=sa_config.NSAMPLE_LIST[k],
+                    mlps=mlps,
+                    use_xyz=True,
+                    dilated_group=sa_config.DILATED_GROUP[k],
+                    aggregation_mlp=aggregation_mlp,
+                    confidence_mlp=confidence_mlp,
+                    num_class=self.num_class))
+            elif self.layer_types[k] == 'Vote_Layer':
+                self.SA_modules.append(pointnet2_modules.Vote_layer(
+                    mlp_list=sa_config.MLPS[k],
+                    pre_channel=channel_out_list[self.layer_inputs[k]],
+                    max_translate_range=self.max_translate_range))
+            channel_out_list.append(channel_out)
+        self.num_point_features = channel_out
+
+    @staticmethod
+    def break_up_pc(pc):
+        batch_idx = pc[:, 0]
+        xyz = pc[:, 1:4].contiguous()
+        features = (pc[:, 4:].contiguous() if pc.size(-1) > 4 else None)
+        return batch_idx, xyz, features
+
+    def forward(self, batch_dict):
+        """batch_dict: batch_size, points (B*N, 1 + 3 + C) [bs_idx, x, y, z, ...] with the same N
+        for every scene (IASSD_backbone.py:137).  Adds the reference's output keys (:188-203)."""
+        batch_size = batch_dict['batch_size']
+        points = batch_dict['points']
+        batch_idx, xyz, features = self.break_up_pc(points)
+        assert points.shape[0] % batch_size == 0, "every scene must hold the same number of points"
+        xyz = xyz.view(batch_size, -1, 3)
+        features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous() \
+            if features is not None else None
+
+        encoder_xyz, encoder_features, sa_ins_preds = [xyz], [features], []
+        encoder_sample_list_id = []
+        encoder_coords = [torch.cat([batch_idx.view(batch_size, -1, 1), xyz], dim=-1)]
+        bidx = batch_idx.view(batch_size, -1)
+
+        li_cls_pred = None
+        sample_list_id = []
+        for i in range(len(self.SA_modules)):
+            xyz_input = encoder_xyz[self.layer_inputs[i]]
+            feature_input = encoder_features[self.layer_inputs[i]]
+            if self.layer_types[i] == 'SA_Layer':
+                ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
+                li_xyz, li_features, li_cls_pred, sample_list_id = self.SA_modules[i](
+                    xyz_input, feature_input, li_cls_pred, ctr_xyz=ctr_xyz)
+            elif self.layer_types[i] == 'Vote_Layer':
+                li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input)
+                centers = li_xyz
+                centers_origin = xyz_select
+                center_origin_batch_idx = bidx[:, :centers_origin.shape[1]]
+                encoder_coords.append(torch.cat([center_origin_batch_idx[..., None].float(),
+                                                 centers_origin.view(batch_size, -1, 3)], dim=-1))
+            encoder_xyz.append(li_xyz)
+            li_batch_idx = bidx[:, :li_xyz.shape[1]]
+            encoder_coords.append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
+            encoder_features.append(li_features)
+            encoder_sample_list_id.append(sample_list_id)
+            if li_cls_pred is not None:
+                li_cls_batch_idx = bidx[:, :li_cls_pred.shape[1]]
+                sa_ins_preds.append(torch.cat([li_cls_batch_idx[..., None].float(),
+                                               li_cls_pred.view(batch_size, -1, li_cls_pred.shape[-1])], dim=-1))
+            else:
+                sa_ins_preds.append([])
+
+        ctr_batch_idx = bidx[:, :li_xyz.shape[1]].contiguous().view(-1)
+        batch_dict['ctr_offsets'] = torch.cat((ctr_batch_idx[:, None].float(), ctr_offsets.contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers'] = torch.cat((ctr_batch_idx[:, None].float(), centers.contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers_origin'] = torch.cat((ctr_batch_idx[:, None].float(), centers_origin.contiguous().view(-1, 3)), dim=1)
+        center_features = encoder_features[-1].permute(0, 2, 1).contiguous().view(-1, encoder_features[-1].shape[1])
+        batch_dict['centers_features'] = center_features
+        batch_dict['ctr_batch_idx'] = ctr_batch_idx
+        batch_dict['encoder_xyz'] = encoder_xyz
+        batch_dict['encoder_coords'] = encoder_coords
+        batch_dict['sa_ins_preds'] = sa_ins_preds
+        batch_dict['encoder_features'] = encoder_features
+        batch_dict['sample_list_id'] = encoder_sample_list_id
+        return batch_dict
+
+
+def build_backbone(cfg_path="once_pda_ssd.yaml", input_channels=None):
+    """IASSD_Backbone from a yaml (this repo's cfgs/ or a reference model yaml)."""
+    from . import config
+    cfg = config.load_yaml(cfg_path)
+    num_class = len(cfg.CLASS_NAMES)
+    if input_channels is None:
+        input_channels = cfg.get('DATA_CONFIG', {}).get('NUM_POINT_FEATURES', 4)
+    return IASSD_Backbone(cfg.MODEL.BACKBONE_3D, num_class=num_class, input_channels=input_channels), cfg

@@ -1,0 +1,132 @@
+"""Workloads for bench.py beyond the bare operator sequence."""
+import time
+
+import numpy as np
+import torch
+
+DEFAULT = "backbone"
+
+
+class BackboneWorkload:
+    """PDA-SSD backbone (IASSD_Backbone, ONCE yaml) forward + backward on synthetic ONCE scenes.
+
+    One step = forward over `batch` scenes of `n_points` points in training mode (batch-stat
+    BatchNorm, as the reference trains) + backward of a scalar loss that touches every backbone
+    output the detection head consumes (centers_features, ctr_offsets, sa_ins_preds), so every
+    parameter receives a gradient.  No optimiser step: the head/loss/optimiser are the "next"
+    rows -- the metric here is the backbone fwd+bwd rate.
+    With world > 1 the model is wrapped in DDP (RCCL gradient all-reduce over xGMI).
+    """
+
+    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml"):
+        from . import synth
+        from .backbone import build_backbone
+        self.B, self.N = batch, n_points
+        self.name = "once16k_b%d_backbone_fwd_bwd" % batch if n_points == 16384 else \
+            "once%d_b%d_backbone_fwd_bwd" % (n_points, batch)
+        self.device = device
+        self.amp = amp
+        self.dtype = "bf16 dense / f32 ops" if amp else "f32"
+        torch.manual_seed(1234)  # same initial weights on every rank
+        model, self.cfg = build_backbone(cfg)
+        self.model = model.to(device).train()
+        self.ddp = None
+        if world > 1:
+            self.ddp = torch.nn.parallel.DistributedDataParallel(
+                self.model, device_ids=[device.index], gradient_as_bucket_view=True)
+        self.points_np = synth.batch_points(batch, n_points, config_id=2 + 10 * rank, dist="L")
+        self.points = torch.from_numpy(self.points_np).to(device)
+        self.fps_events = []
+        self.record = False
+        self._hook_fps()
+
+    def _hook_fps(self):
+        # time the D-FPS launches with events on the launch stream (roofline leg of bench.py)
+        from . import pointnet2_utils as pu
+        orig = pu.FarthestPointSampling.apply
+        wl = self
+
+        def timed(xyz, npoint):
+            if not wl.record:
+                return orig(xyz, npoint)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig(xyz, npoint)
+            e1.record()
+            wl.fps_events.append((e0, e1, xyz.shape[1], npoint))
+            return out
+        pu.furthest_point_sample = pu.farthest_point_sample = timed
+
+    @staticmethod
+    def loss_of(bd):
+        loss = bd['centers_features'].float().pow(2).mean() + bd['ctr_offsets'][:, 1:].pow(2).mean()
+        for p in bd['sa_ins_preds']:
+            if not isinstance(p, list):
+                loss = loss + p[..., 1:].float().pow(2).mean()
+        return loss
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        for p in self.model.parameters():
+            p.grad = None
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+            bd = model({'batch_size': self.B, 'points': self.points})
+        loss = self.loss_of(bd)
+        loss.backward()
+        return loss
+
+    def fps_shape(self):
+        if self.fps_events:
+            return self.fps_events[0][2], self.fps_events[0][3]
+        return self.N, 4096
+
+    def cpu_baseline(self, budget_s=30.0):
+        """Same step on the host cores: this repo's model code with the operator extension
+        replaced by the CPU oracle (kind 'port'), dense layers on torch CPU.  One scene pair is
+        too slow for a default run, so the sample is ONE step over ONE scene."""
+        import oracle
+        from . import pointnet2_utils as pu
+        from .backbone import build_backbone
+
+        class Stub:
+            pass
+        stub = Stub()
+        for name in ["ball_query_wrapper", "ball_query_dilated_wrapper", "group_points_wrapper",
+                     "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
+                     "farthest_point_sampling_wrapper", "furthest_point_sampling_with_dist_wrapper",
+                     "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+            def mk(fn):
+                return lambda *a: fn(*[x.numpy() if isinstance(x, torch.Tensor) else x for x in a])
+            setattr(stub, name, mk(getattr(oracle, name)))
+
+        def bq_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
+            for r, ns, idx in zip(radii, nsamples, idxs):
+                oracle.ball_query_wrapper(b, n, m, r, ns, new_xyz.numpy(), xyz.numpy(), idx.numpy())
+            return 1
+        stub.ball_query_multi = bq_multi
+        saved = pu.pointnet2
+        pu.pointnet2 = stub
+        try:
+            torch.manual_seed(1234)
+            model, _ = build_backbone("once_pda_ssd.yaml")
+            model.train()
+            pts = torch.from_numpy(self.points_np[: self.N].copy())
+            nthreads = max(oracle.num_threads(), torch.get_num_threads())
+            t0 = time.perf_counter()
+            bd = model({'batch_size': 1, 'points': pts})
+            self.loss_of(bd).backward()
+            dt = time.perf_counter() - t0
+        finally:
+            pu.pointnet2 = saved
+        return dict(value=1.0 / dt, unit="scenes/s", cores=nthreads, kind="port",
+                    sample="1 step over 1 scene (scene 0 of the GPU batch, %d pts): this repo's backbone "
+                           "with the extension replaced by oracle/libpda_oracle.so and dense layers on "
+                           "torch CPU, fwd+bwd, %.1f s" % (self.N, dt))
+
+
+def create(name, batch, n_points, device, rank, world):
+    if name == "backbone":
+        return BackboneWorkload(batch, n_points, device, rank, world, amp=False)
+    if name == "backbone_bf16":
+        return BackboneWorkload(batch, n_points, device, rank, world, amp=True)
+    raise ValueError("unknown workload %r" % name)

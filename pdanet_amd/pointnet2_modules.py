@@ -1,0 +1,464 @@
+"""Set-abstraction layer modules of PDA-SSD, restated on top of the gfx950 operators.
+
+Mirrors, by name, constructor signature, forward signature, return values and state-dict key
+layout, the classes of /root/reference/pcdet/ops/pointnet2/pointnet2_batch/:
+  TransformerEncoderLayerPreNorm                  PointFormer.py:7-38
+  PointnetSAModuleMSG_WithSampling                pointnet2_modules.py:1417-1686  (vanilla SA)
+  PointnetSAModuleMSG_WithSampling_Ellipsoid      pointnet2_modules.py:541-954    (the PDA layer)
+  DensityNet / PointConvDensitySetAbstraction     pointnet2_modules.py:958-1006
+  Vote_layer                                      pointnet2_modules.py:1689-1753
+  PointnetFPModule                                pointnet2_modules.py:1776-1824
+so a reference checkpoint's ``backbone_3d.*`` keys load with strict=True.
+
+What is done differently (results unchanged):
+  * all scales of a layer share ONE multi-radius ball query pass (pda_ball_query_multi);
+  * xyz^T is transposed once per layer, not once per grouper;
+  * the sampling stage skips the (B,N,C) feature transpose the reference materialises and
+    never uses for D-FPS / ctr-aware sampling (pointnet2_modules.py:1554);
+  * optional fused group->MLP->max-pool path for the vanilla SA layers (see fused_ops.py).
+"""
+from typing import List
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import pointnet2_utils
+
+
+class TransformerEncoderLayerPreNorm(nn.Module):
+    """PointFormer.py:7-38.  NB despite the name the residual is taken from the NORMALISED
+    input (src = norm1(src); src = src + attn(src)), which is what the reference does."""
+
+    def __init__(self, d_model, nhead, dim_feedforward=2048, dropout=0.1, activation="relu"):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.dropout = nn.Dropout(dropout, inplace=True)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout1 = nn.Dropout(dropout, inplace=True)
+        self.dropout2 = nn.Dropout(dropout, inplace=True)
+        self.activation = nn.ReLU(inplace=True)
+
+    def forward(self, src, src_mask=None, src_key_padding_mask=None):
+        src = self.norm1(src)  # (K, B*N, C)
+        src2, _ = self.self_attn(src, src, src, attn_mask=src_mask,
+                                 key_padding_mask=src_key_padding_mask, need_weights=False)
+        src = src + self.dropout1(src2)
+        src = self.norm2(src)
+        src2 = self.linear2(self.dropout(self.activation(self.linear1(src))))
+        src = src + self.dropout2(src2)
+        return src
+
+
+def calc_square_dist(a, b):
+    """pointnet2_modules.py:19-43: |a|^2 + |b|^2 - 2 a.b  -> (bs, n, m)."""
+    a_sq = torch.sum(a * a, dim=-1).unsqueeze(2)
+    b_sq = torch.sum(b * b, dim=-1).unsqueeze(1)
+    return a_sq + b_sq - 2.0 * torch.matmul(a, b.transpose(1, 2))
+
+
+def _partition_fps(xyz_tmp, npoint, key_fn, batch):
+    """ds-FPS / ry-FPS (pointnet2_modules.py:1595-1642): sort each scene by a scalar key, cut
+    into 4 equal parts, D-FPS npoint/4 in every part, map back to scene indices."""
+    part_num = 4
+    xyz_div, idx_div = [], []
+    for per_xyz in xyz_tmp:
+        _, order = key_fn(per_xyz).sort(dim=0, descending=False)
+        xyz_div.append(per_xyz[order].view(part_num, -1, 3))
+        idx_div.append(order.view(part_num, -1))
+    xyz_div = torch.cat(xyz_div, dim=0).contiguous()
+    idx_div = torch.cat(idx_div, dim=0)
+    idx_sampled = pointnet2_utils.furthest_point_sample(xyz_div, npoint // part_num)
+    picked = [idx_per[s.long()] for s, idx_per in zip(idx_sampled, idx_div)]
+    return torch.cat(picked, dim=-1).reshape(batch, npoint).int()
+
+
+def sample_points(xyz, features, cls_features, sample_type_list, sample_range_list, npoint_list):
+    """The sampling stage shared by both SA layer classes
+    (pointnet2_modules.py:1542-1646 == :738-841).  Returns sampled_idx (B, sum npoint) int32."""
+    sampled_idx_list = []
+    last_sample_end_index = 0
+    for i in range(len(sample_type_list)):
+        sample_type = sample_type_list[i]
+        sample_range = sample_range_list[i]
+        npoint = npoint_list[i]
+        if npoint <= 0:
+            continue
+        if sample_range == -1:
+            sl = slice(last_sample_end_index, None)
+        else:
+            sl = slice(last_sample_end_index, sample_range)
+            last_sample_end_index += sample_range
+        xyz_tmp = xyz[:, sl, :]
+        cls_features_tmp = cls_features[:, sl, :] if cls_features is not None else None
+
+        def feature_tmp():  # only the feature-distance samplers need it
+            return features.transpose(1, 2)[:, sl, :].contiguous()
+
+        n_tmp = xyz_tmp.shape[1]
+        if n_tmp <= npoint:  # no downsampling
+            sample_idx = torch.arange(n_tmp, device=xyz.device, dtype=torch.int32).unsqueeze(0) \
+                .expand(xyz_tmp.shape[0], n_tmp).contiguous()
+        elif ('cls' in sample_type) or ('ctr' in sample_type):
+            cls_features_max, _ = cls_features_tmp.max(dim=-1)
+            score_pred = torch.sigmoid(cls_features_max)  # (B, N)
+            _, sample_idx = torch.topk(score_pred, npoint, dim=-1)
+            sample_idx = sample_idx.int()
+        elif 'D-FPS' in sample_type or 'DFS' in sample_type:
+            sample_idx = pointnet2_utils.furthest_point_sample(xyz_tmp.contiguous(), npoint)
+        elif 'F-FPS' in sample_type or 'FFS' in sample_type:
+            f = torch.cat([xyz_tmp, feature_tmp()], dim=-1)
+            sample_idx = pointnet2_utils.furthest_point_sample_with_dist(calc_square_dist(f, f).contiguous(), npoint)
+        elif sample_type == 'FS':
+            f = torch.cat([xyz_tmp, feature_tmp()], dim=-1)
+            idx1 = pointnet2_utils.furthest_point_sample_with_dist(calc_square_dist(f, f).contiguous(), npoint)
+            idx2 = pointnet2_utils.furthest_point_sample(xyz_tmp.contiguous(), npoint)
+            sample_idx = torch.cat([idx1, idx2], dim=-1)
+        elif 'Rand' in sample_type:
+            sample_idx = torch.randperm(n_tmp, device=xyz.device)[None, :npoint].int().repeat(xyz_tmp.shape[0], 1)
+        elif sample_type in ('ds_FPS', 'ds-FPS'):
+            sample_idx = _partition_fps(xyz_tmp, npoint, lambda p: p.norm(dim=-1) - 5, xyz.shape[0])
+        elif sample_type in ('ry_FPS', 'ry-FPS'):
+            sample_idx = _partition_fps(xyz_tmp, npoint, lambda p: torch.atan(p[:, 0] / p[:, 1]), xyz.shape[0])
+        else:
+            raise NotImplementedError("sample type %r" % (sample_type,))
+        sampled_idx_list.append(sample_idx)
+    return torch.cat(sampled_idx_list, dim=-1).contiguous()
+
+
+def _conv_bn_relu_1d(channels_in, spec):
+    layers = []
+    for c in spec:
+        layers.extend([nn.Conv1d(channels_in, c, kernel_size=1, bias=False), nn.BatchNorm1d(c), nn.ReLU()])
+        channels_in = c
+    return layers, channels_in
+
+
+def _build_heads(module, out_channels, aggregation_mlp, confidence_mlp, num_class, have_branches):
+    """aggregation_layer / confidence_layers exactly as pointnet2_modules.py:1495-1524."""
+    if (aggregation_mlp is not None) and (len(aggregation_mlp) != 0) and have_branches:
+        layers, out_channels = _conv_bn_relu_1d(out_channels, aggregation_mlp)
+        module.aggregation_layer = nn.Sequential(*layers)
+    else:
+        module.aggregation_layer = None
+    if (confidence_mlp is not None) and (len(confidence_mlp) != 0):
+        layers, out_channels = _conv_bn_relu_1d(out_channels, confidence_mlp)
+        layers.append(nn.Conv1d(out_channels, num_class, kernel_size=1, bias=True))
+        module.confidence_layers = nn.Sequential(*layers)
+    else:
+        module.confidence_layers = None
+
+
+class _SAModuleBase(nn.Module):
+    def _ball_queries(self, xyz, new_xyz):
+        """One pass over the points for every scale of this layer (None for non-ball groupers)."""
+        if len(self.groupers) == 0 or not hasattr(self.groupers[0], "radius"):
+            return [None] * len(self.groupers)
+        return pointnet2_utils.ball_query_multi([g.radius for g in self.groupers],
+                                                [g.nsample for g in self.groupers], xyz, new_xyz)
+
+
+class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
+    """Vanilla SA layer with sampling + multi-scale grouping (pointnet2_modules.py:1417-1686):
+    sample -> per scale [QueryAndGroup -> (Conv2d 1x1 no bias, BN2d, ReLU)*k -> max over nsample]
+    -> concat -> aggregation Conv1d+BN+ReLU -> optional confidence head."""
+
+    def __init__(self, *, npoint_list: List[int], sample_range_list: List[int], sample_type_list: List[str],
+                 radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
+                 dilated_group=False, pool_method='max_pool', aggregation_mlp: List[int],
+                 confidence_mlp: List[int], num_class):
+        super().__init__()
+        self.sample_type_list = sample_type_list
+        self.sample_range_list = sample_range_list
+        self.dilated_group = dilated_group
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint_list = npoint_list
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        out_channels = 0
+        for i in range(len(radii)):
+            radius, nsample = radii[i], nsamples[i]
+            if npoint_list is None:
+                self.groupers.append(pointnet2_utils.GroupAll(use_xyz))
+            elif self.dilated_group:
+                min_radius = 0. if i == 0 else radii[i - 1]
+                self.groupers.append(pointnet2_utils.QueryDilatedAndGroup(radius, min_radius, nsample, use_xyz=use_xyz))
+            else:
+                self.groupers.append(pointnet2_utils.QueryAndGroup(radius, nsample, use_xyz=use_xyz))
+            mlp_spec = list(mlps[i])
+            if use_xyz:
+                mlp_spec[0] += 3
+            shared_mlps = []
+            for k in range(len(mlp_spec) - 1):
+                shared_mlps.extend([nn.Conv2d(mlp_spec[k], mlp_spec[k + 1], kernel_size=1, bias=False),
+                                    nn.BatchNorm2d(mlp_spec[k + 1]), nn.ReLU()])
+            self.mlps.append(nn.Sequential(*shared_mlps))
+            out_channels += mlp_spec[-1]
+        self.pool_method = pool_method
+        _build_heads(self, out_channels, aggregation_mlp, confidence_mlp, num_class, len(self.mlps) > 0)
+        self.fused = None  # set by fused_ops.enable_fused(): group->MLP->max-pool in one HIP kernel
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
+                new_xyz=None, ctr_xyz=None):
+        """xyz (B,N,3), features (B,C,N), cls_features (B,N,num_class) ->
+        new_xyz (B,M,3), new_features (B,C',M), cls_features (B,M,num_class)|None, sampled_idx"""
+        sampled_idx_list = []
+        if ctr_xyz is None:
+            sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
+                                             self.sample_range_list, self.npoint_list)
+            xyz_flipped = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
+        else:
+            new_xyz = ctr_xyz
+
+        if len(self.groupers) > 0:
+            new_features_list = []
+            plain_ball = (not self.dilated_group) and isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup)
+            idxs = self._ball_queries(xyz, new_xyz) if plain_ball else [None] * len(self.groupers)
+            for i in range(len(self.groupers)):
+                if self.fused is not None and plain_ball and self.pool_method == 'max_pool':
+                    pooled = self.fused(i, self, xyz, new_xyz, features, idxs[i])  # (B, mlp[-1], npoint)
+                    new_features_list.append(pooled)
+                    continue
+                if plain_ball:
+                    new_features = self.groupers[i](xyz, new_xyz, features, idx=idxs[i])
+                else:
+                    new_features = self.groupers[i](xyz, new_xyz, features)  # (B, C, npoint, nsample)
+                new_features = self.mlps[i](new_features)  # (B, mlp[-1], npoint, nsample)
+                if self.pool_method == 'max_pool':
+                    new_features = F.max_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+                elif self.pool_method == 'avg_pool':
+                    new_features = F.avg_pool2d(new_features, kernel_size=[1, new_features.size(3)])
+                else:
+                    raise NotImplementedError
+                new_features_list.append(new_features.squeeze(-1))  # (B, mlp[-1], npoint)
+            new_features = torch.cat(new_features_list, dim=1)
+            if self.aggregation_layer is not None:
+                new_features = self.aggregation_layer(new_features)
+        else:
+            new_features = pointnet2_utils.gather_operation(features, sampled_idx_list).contiguous()
+
+        if self.confidence_layers is not None:
+            cls_features = self.confidence_layers(new_features).transpose(1, 2)
+        else:
+            cls_features = None
+        return new_xyz, new_features, cls_features, sampled_idx_list
+
+
+class DensityNet(nn.Module):
+    """pointnet2_modules.py:958-981: 1x1 convs 1->16->8->1 WITH bias, BN after each, and ReLU
+    after EVERY layer including the last (the sigmoid branch `i == len(mlp_convs)` at :976 can
+    never be taken)."""
+
+    def __init__(self, hidden_unit=[16, 8]):
+        super().__init__()
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        self.mlp_convs.append(nn.Conv2d(1, hidden_unit[0], 1))
+        self.mlp_bns.append(nn.BatchNorm2d(hidden_unit[0]))
+        for i in range(1, len(hidden_unit)):
+            self.mlp_convs.append(nn.Conv2d(hidden_unit[i - 1], hidden_unit[i], 1))
+            self.mlp_bns.append(nn.BatchNorm2d(hidden_unit[i]))
+        self.mlp_convs.append(nn.Conv2d(hidden_unit[-1], 1, 1))
+        self.mlp_bns.append(nn.BatchNorm2d(1))
+
+    def forward(self, density_scale):
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            density_scale = F.relu(bn(conv(density_scale)))
+        return density_scale
+
+
+class PointConvDensitySetAbstraction(nn.Module):
+    """pointnet2_modules.py:983-1006: density / per-group max -> DensityNet."""
+
+    def __init__(self, bandwidth):
+        super().__init__()
+        self.densitynet = DensityNet()
+        self.bandwidth = bandwidth
+
+    def forward(self, grouped_density):  # (B, 1, npoint, nsample)
+        inverse_max_density = grouped_density.max(dim=3, keepdim=True)[0]
+        return self.densitynet(grouped_density / inverse_max_density)
+
+
+class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
+    """The PDA layer (pointnet2_modules.py:541-954).  Per scale with C = mlp_spec[0]:
+    grouper -> [xyz(3) | density(1) | direction(3) | features(C)];
+    position_mlp(12->C/2->C) on [centre, nbr, centre-nbr, direction];
+    global_mlps(C+3->C->C) on the centre's own [xyz, feature], repeated over nsample;
+    DensityNet on density/max; concat [rppe, f*density, f, global] (D = 4C);
+    TransformerEncoderLayerPreNorm(D, 4 heads, ff = 2C) over sequences of nsample;
+    max over nsample; fin_conv(4C->2C->mlp_spec[-1]).
+    Only mlp_spec[0] and mlp_spec[-1] are used (:628-671); use_xyz adds nothing (:674-675)."""
+
+    def __init__(self, *, npoint_list: List[int], sample_range_list: List[int], sample_type_list: List[str],
+                 radii: List[float], nsamples: List[int], mlps: List[List[int]], use_xyz: bool = True,
+                 dilated_group=False, pool_method='max_pool', aggregation_mlp: List[int],
+                 confidence_mlp: List[int], num_class):
+        super().__init__()
+        self.sample_type_list = sample_type_list
+        self.sample_range_list = sample_range_list
+        self.dilated_group = dilated_group
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.npoint_list = npoint_list
+        self.groupers = nn.ModuleList()
+        self.groupers_global = nn.ModuleList()  # present (and empty) in the reference too (:581)
+        self.nsamples = nsamples
+        self.point_density = nn.ModuleList()
+        self.position_mlp = nn.ModuleList()
+        self.Local_pointformer = nn.ModuleList()
+        self.fin_conv = nn.ModuleList()
+        self.global_mlps = nn.ModuleList()
+
+        def conv_bn_relu2d(cin, cout):
+            return [nn.Conv2d(cin, cout, kernel_size=1, bias=False), nn.BatchNorm2d(cout), nn.ReLU()]
+
+        out_channels = 0
+        for i in range(len(radii)):
+            radius, nsample = radii[i], nsamples[i]
+            if npoint_list is None:
+                self.groupers.append(pointnet2_utils.GroupAll(use_xyz))
+            elif self.dilated_group:
+                min_radius = 0. if i == 0 else radii[i - 1]
+                self.groupers.append(pointnet2_utils.QueryDilatedAndGroup(radius, min_radius, nsample, use_xyz=use_xyz))
+            else:
+                self.groupers.append(pointnet2_utils.QueryAndGroup_alone_grouped_density_directional(
+                    radius, nsample, use_xyz=use_xyz))
+            c = mlps[i][0]
+            self.Local_pointformer.append(TransformerEncoderLayerPreNorm(
+                d_model=c * 4, dim_feedforward=2 * c, dropout=0.0, nhead=4))
+            self.position_mlp.append(nn.Sequential(*(conv_bn_relu2d(9 + 3, c // 2) + conv_bn_relu2d(c // 2, c))))
+            self.global_mlps.append(nn.Sequential(*(conv_bn_relu2d(c + 3, c) + conv_bn_relu2d(c, c))))
+            self.point_density.append(PointConvDensitySetAbstraction(radius))
+            self.fin_conv.append(nn.Sequential(*(conv_bn_relu2d(4 * c, 2 * c) + conv_bn_relu2d(2 * c, mlps[i][-1]))))
+            out_channels += mlps[i][-1]
+        self.pool_method = pool_method
+        _build_heads(self, out_channels, aggregation_mlp, confidence_mlp, num_class, len(self.fin_conv) > 0)
+
+    def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
+                new_xyz=None, ctr_xyz=None):
+        sampled_idx_list = []
+        if ctr_xyz is None:
+            sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
+                                             self.sample_range_list, self.npoint_list)
+            xyz_flipped = xyz.transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
+            new_xyz_feature = pointnet2_utils.gather_operation(features, sampled_idx_list).transpose(1, 2).contiguous()
+        else:
+            new_xyz = ctr_xyz  # the reference has no centre features on this branch either (:850-851)
+
+        if len(self.groupers) > 0:
+            new_features_list = []
+            # (B, 3 + C, npoint, 1): the sampled centre's own coordinates and feature (:856)
+            global_feature = torch.cat([new_xyz, new_xyz_feature], dim=-1).transpose(1, 2).unsqueeze(dim=-1)
+            directional = isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional)
+            idxs = self._ball_queries(xyz, new_xyz) if directional else [None] * len(self.groupers)
+            B, npoint = new_xyz.shape[0], new_xyz.shape[1]
+            for i in range(len(self.groupers)):
+                if directional:
+                    new_features = self.groupers[i](xyz, new_xyz, features, idx=idxs[i])
+                else:
+                    new_features = self.groupers[i](xyz, new_xyz, features)
+                K_sample = self.nsamples[i]
+                new_xyz_k = new_features[:, :3]                    # (B, 3, npoint, ns) absolute neighbour xyz
+                grouped_density_feature = new_features[:, 3:4]     # (B, 1, npoint, ns)
+                directional_vectors = new_features[:, 4:7]         # (B, 3, npoint, ns)
+                new_xyz_K_feature = new_features[:, 7:]            # (B, C, npoint, ns)
+
+                global_feature_k = self.global_mlps[i](global_feature).expand(-1, -1, -1, K_sample)
+                density_scale_score = self.point_density[i](grouped_density_feature.contiguous())
+                new_density_score_feature = new_xyz_K_feature * density_scale_score
+
+                # relative point position encoding, channel order of :907-913, built channel-major
+                # directly (the reference builds it (B,np,ns,12) and permutes)
+                extended_coords = new_xyz.transpose(1, 2).unsqueeze(-1).expand(B, 3, npoint, K_sample)
+                rppe = torch.cat([extended_coords, new_xyz_k, extended_coords - new_xyz_k, directional_vectors], dim=1)
+                rppe = self.position_mlp[i](rppe)
+
+                input_features = torch.cat([rppe, new_density_score_feature, new_xyz_K_feature, global_feature_k], dim=1)
+                Bq, D, np_, ns = input_features.shape
+                # (B, D, np, ns) -> (ns, B*np, D)
+                input_features = input_features.permute(3, 0, 2, 1).reshape(ns, Bq * np_, D)
+                transformed = self.Local_pointformer[i](input_features)  # (ns, B*np, D)
+                # max over nsample == F.max_pool2d(kernel=[1, ns]) of the reference (:931)
+                output_features = transformed.max(dim=0)[0].view(Bq, np_, D).permute(0, 2, 1).unsqueeze(-1)
+                output_features = self.fin_conv[i](output_features.contiguous()).squeeze(-1)
+                new_features_list.append(output_features)
+            new_features = torch.cat(new_features_list, dim=1)
+            if self.aggregation_layer is not None:
+                new_features = self.aggregation_layer(new_features)
+        else:
+            new_features = pointnet2_utils.gather_operation(features, sampled_idx_list).contiguous()
+
+        if self.confidence_layers is not None:
+            cls_features = self.confidence_layers(new_features).transpose(1, 2)
+        else:
+            cls_features = None
+        return new_xyz, new_features, cls_features, sampled_idx_list
+
+
+class Vote_layer(nn.Module):
+    """Light voting module with limitation (pointnet2_modules.py:1689-1753)."""
+
+    def __init__(self, mlp_list, pre_channel, max_translate_range):
+        super().__init__()
+        self.mlp_list = mlp_list
+        if len(mlp_list) > 0:
+            # the reference re-creates `shared_mlps` inside its loop (:1695-1704), so only the LAST
+            # entry of mlp_list survives into mlp_modules, fed by the channel count of the one before
+            shared_mlps = []
+            for i in range(len(mlp_list)):
+                shared_mlps = [nn.Conv1d(pre_channel, mlp_list[i], kernel_size=1, bias=False),
+                               nn.BatchNorm1d(mlp_list[i]), nn.ReLU()]
+                pre_channel = mlp_list[i]
+            self.mlp_modules = nn.Sequential(*shared_mlps)
+        else:
+            self.mlp_modules = None
+        self.ctr_reg = nn.Conv1d(pre_channel, 3, kernel_size=1)
+        self.max_offset_limit = torch.tensor(max_translate_range).float() if max_translate_range is not None else None
+
+    def forward(self, xyz, features):
+        xyz_select = xyz
+        new_features = self.mlp_modules(features) if self.mlp_modules is not None else features
+        ctr_offsets = self.ctr_reg(new_features).transpose(1, 2)  # (B, N, 3)
+        new_features = ctr_offsets[..., 3:]
+        ctr_offsets = ctr_offsets[..., :3]
+        if self.max_offset_limit is not None:
+            lim = self.max_offset_limit.to(xyz_select.device).view(1, 1, 3)
+            limited = torch.where(ctr_offsets > lim, lim, ctr_offsets)
+            limited = torch.where(limited < -lim, -lim, limited)
+            vote_xyz = xyz_select + limited
+        else:
+            vote_xyz = xyz_select + ctr_offsets
+        return vote_xyz, new_features, xyz_select, ctr_offsets
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: three_nn + inverse-distance three_interpolate + shared MLP
+    (pointnet2_modules.py:1776-1824).  Not used by IASSD_Backbone; north_star names the ops."""
+
+    def __init__(self, *, mlp: List[int], bn: bool = True):
+        super().__init__()
+        shared_mlps = []
+        for k in range(len(mlp) - 1):
+            shared_mlps.extend([nn.Conv2d(mlp[k], mlp[k + 1], kernel_size=1, bias=False),
+                                nn.BatchNorm2d(mlp[k + 1]), nn.ReLU()])
+        self.mlp = nn.Sequential(*shared_mlps)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            dist_recip = 1.0 / (dist + 1e-8)
+            norm = torch.sum(dist_recip, dim=2, keepdim=True)
+            weight = dist_recip / norm
+            interpolated_feats = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated_feats = known_feats.expand(*known_feats.size()[0:2], unknown.size(1))
+        if unknow_feats is not None:
+            new_features = torch.cat([interpolated_feats, unknow_feats], dim=1)
+        else:
+            new_features = interpolated_feats
+        return self.mlp(new_features.unsqueeze(-1)).squeeze(-1)
