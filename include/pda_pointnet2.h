@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 3
+#define PDA_POINTNET2_ABI_VERSION 4
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -115,6 +115,27 @@ int pda_three_interpolate(const float *points, const int32_t *idx, const float *
 int pda_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight,
                                float *grad_points, int b, int c, int n, int m,
                                pda_stream_t stream);
+
+/* ---- fused set-abstraction scale (MI355X extension) --------------------------------- */
+/* One scale of a vanilla SA layer in inference form, fused into one kernel:
+ *   QueryAndGroup (pointnet2_utils.py:671-704) -> [Conv2d 1x1 no bias -> BatchNorm2d (folded
+ *   into scale/shift) -> ReLU] x 3 -> max over nsample   (pointnet2_modules.py:1657-1670).
+ * No reference extension entry corresponds to it: the reference runs this chain as ~12 torch /
+ * cuDNN kernels over materialised (B,C,npoint,nsample) tensors.  f32 MFMA, f32 accumulate.
+ *   dims[4] = {3 + c, c1, c2, c3};  wf[l] = weights of layer l packed by
+ *   pda_sa_mlp_pack_weights (layer 0: first_layer = 1);  scale[l], shift[l]: folded BN, padded
+ *   with zeros to a multiple of 32 entries;  out (b, c3, m).
+ * Returns PDA_ERR_UNSUPPORTED for chains no kernel was built for (callers then run the unfused
+ * operator sequence) -- see the case table in csrc/sa_mlp.hip. */
+int pda_sa_mlp_maxpool(const float *xyz, const float *new_xyz, const float *features,
+                       const int32_t *idx, float *out, int b, int n, int m, int c, int nsample,
+                       const int32_t *dims, const float *const *wf, const float *const *scale,
+                       const float *const *shift, pda_stream_t stream);
+/* Number of floats pda_sa_mlp_pack_weights writes for a (rows x cols) layer. */
+int pda_sa_mlp_packed_size(int rows, int cols, int first_layer);
+/* Re-orders a row-major (rows x cols) fp32 weight matrix into MFMA A-fragment order. */
+int pda_sa_mlp_pack_weights(const float *w, float *wf, int rows, int cols, int first_layer,
+                            pda_stream_t stream);
 
 #ifdef __cplusplus
 }

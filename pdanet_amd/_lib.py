@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -29,6 +29,10 @@ SIGNATURES = {
     "pda_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pda_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_sa_mlp_maxpool": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),
+                           ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp],
+    "pda_sa_mlp_packed_size": [_i, _i, _i],
+    "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
 

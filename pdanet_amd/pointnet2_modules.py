@@ -219,10 +219,12 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
             plain_ball = (not self.dilated_group) and isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup)
             idxs = self._ball_queries(xyz, new_xyz) if plain_ball else [None] * len(self.groupers)
             for i in range(len(self.groupers)):
-                if self.fused is not None and plain_ball and self.pool_method == 'max_pool':
-                    pooled = self.fused(i, self, xyz, new_xyz, features, idxs[i])  # (B, mlp[-1], npoint)
-                    new_features_list.append(pooled)
-                    continue
+                if self.fused is not None and plain_ball and self.pool_method == 'max_pool' \
+                        and not self.training and not torch.is_grad_enabled():
+                    pooled = self.fused(i, self, xyz, new_xyz, features, idxs[i])  # (B, mlp[-1], npoint) | None
+                    if pooled is not None:
+                        new_features_list.append(pooled)
+                        continue
                 if plain_ball:
                     new_features = self.groupers[i](xyz, new_xyz, features, idx=idxs[i])
                 else:
