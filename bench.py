@@ -137,15 +137,12 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from pdanet_amd import parallel
+    rank, local_rank, world = parallel.env_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)  # backend "nccl" is RCCL on ROCm
+    parallel.init_distributed("nccl", device)  # backend "nccl" is RCCL on ROCm; no-op for 1 GPU
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
 
     workload = args.workload
@@ -162,9 +159,7 @@ def main():
         wl = bench_workloads.create(workload, args.batch, args.points, device, rank, world)
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        parallel.barrier(device)
 
     for _ in range(args.warmup):
         wl.step()
@@ -176,17 +171,24 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     wl.record = False
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = parallel.max_over_ranks(dt, device)
 
-    # dominant sampling kernel: FPS, timed live with events on the launch stream
-    n, m = wl.fps_shape()
-    fps_ms = [ev[0].elapsed_time(ev[1]) for ev in wl.fps_events if (ev[2], ev[3]) == (n, m)]
-    fps_avg_s = (sum(fps_ms) / max(1, len(fps_ms))) * 1e-3
-    alg_bytes = fps_algorithmic_bytes(n, m) * args.batch
-    achieved = alg_bytes / fps_avg_s / 1e9 if fps_avg_s > 0 else 0.0
+    roof = wl.roofline() if hasattr(wl, "roofline") else None
+    if roof is None:
+        # dominant sampling kernel: FPS, timed live with events on the launch stream
+        n, m = wl.fps_shape()
+        fps_ms = [ev[0].elapsed_time(ev[1]) for ev in wl.fps_events if (ev[2], ev[3]) == (n, m)]
+        fps_avg_s = (sum(fps_ms) / max(1, len(fps_ms))) * 1e-3
+        alg_bytes = fps_algorithmic_bytes(n, m) * args.batch
+        achieved = alg_bytes / fps_avg_s / 1e9 if fps_avg_s > 0 else 0.0
+        roof = {
+            "kernel": "fps_reg_kernel (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_ms": fps_avg_s * 1e3,
+            "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene) / kernel time; the kernel keeps "
+                    "the scene in registers, so real HBM traffic is the compulsory N*16+m*4 bytes",
+        }
 
     scenes = args.batch * world * args.steps
     line = {
@@ -204,14 +206,7 @@ def main():
         "data": "synthetic",
         "config": {"workload": wl.name, "scenes_per_gpu": args.batch, "points_per_scene": args.points,
                    "parallelism": "dp%d" % world},
-        "roofline": {
-            "kernel": "fps_reg_kernel (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-            "avg_launch_ms": fps_avg_s * 1e3,
-            "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene) / kernel time; the kernel keeps "
-                    "the scene in registers, so real HBM traffic is the compulsory N*16+m*4 bytes",
-        },
+        "roofline": roof,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

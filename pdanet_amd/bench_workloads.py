@@ -30,10 +30,8 @@ class BackboneWorkload:
         torch.manual_seed(1234)  # same initial weights on every rank
         model, self.cfg = build_backbone(cfg)
         self.model = model.to(device).train()
-        self.ddp = None
-        if world > 1:
-            self.ddp = torch.nn.parallel.DistributedDataParallel(
-                self.model, device_ids=[device.index], gradient_as_bucket_view=True)
+        from . import parallel
+        self.ddp = parallel.wrap_ddp(self.model, device) if world > 1 else None
         self.points_np = synth.batch_points(batch, n_points, config_id=2 + 10 * rank, dist="L")
         self.points = torch.from_numpy(self.points_np).to(device)
         self.fps_events = []
@@ -124,7 +122,55 @@ class BackboneWorkload:
                            "torch CPU, fwd+bwd, %.1f s" % (self.N, dt))
 
 
+class BackboneInferWorkload(BackboneWorkload):
+    """BASELINE configs[1] literally: PDA-SSD backbone FORWARD (eval BatchNorm, no_grad) with
+    the fused SA-scale kernel on layers 0 and 5."""
+
+    def __init__(self, batch, n_points, device, rank, world):
+        super().__init__(batch, n_points, device, rank, world, amp=False)
+        from . import fused_ops
+        self.fused_ops = fused_ops
+        self.name = self.name.replace("fwd_bwd", "fwd_eval_fused")
+        self.model.eval()
+        fused_ops.enable_fused(self.model)
+        self.ddp = None
+        self.sa_events = []
+
+    def step(self):
+        self.fused_ops.PROFILE = self.sa_events if self.record else None
+        with torch.no_grad():
+            bd = self.model({'batch_size': self.B, 'points': self.points})
+        self.fused_ops.PROFILE = None
+        return bd['centers_features']
+
+    def roofline(self):
+        """Dominant fused kernel = the launch shape with the largest mean duration."""
+        by = {}
+        for e0, e1, flops, dims, ns in self.sa_events:
+            by.setdefault((dims, ns), []).append((e0.elapsed_time(e1) * 1e-3, flops))
+        if not by:
+            return None
+        stats = {k: (sum(t for t, _ in v) / len(v), v[0][1]) for k, v in by.items()}
+        (dims, ns), (t, flops) = max(stats.items(), key=lambda kv: kv[1][0])
+        l5 = {k: v for k, v in stats.items() if k[0][0] > 100}
+        l5_t, l5_f = sum(v[0] for v in l5.values()), sum(v[1] for v in l5.values())
+        peak = 157.3  # TFLOP/s f32 matrix, MI355X_MICROARCH.md
+        return {"kernel": "sa_mlp_kernel %s ns=%d (%d scenes/launch)" % ("->".join(map(str, dims)), ns, self.B),
+                "bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / peak, "traffic": None, "avg_launch_ms": t * 1e3,
+                "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32); layer 5, all scales: %.1f GFLOP in %.3f ms = "
+                        "%.1f TFLOP/s = %.1f %% of peak" % (l5_f / 1e9, l5_t * 1e3, l5_f / l5_t / 1e12,
+                                                            100 * l5_f / l5_t / 1e12 / peak) if l5_t > 0 else ""}
+
+    def cpu_baseline(self, budget_s=30.0):
+        base = super().cpu_baseline(budget_s)
+        base["sample"] += " (training-mode fwd+bwd step; the inference forward alone is ~1/3 of it)"
+        return base
+
+
 def create(name, batch, n_points, device, rank, world):
+    if name == "backbone_infer":
+        return BackboneInferWorkload(batch, n_points, device, rank, world)
     if name == "backbone":
         return BackboneWorkload(batch, n_points, device, rank, world, amp=False)
     if name == "backbone_bf16":

@@ -15,6 +15,8 @@ from . import _lib
 from .pointnet2_modules import PointnetSAModuleMSG_WithSampling
 
 PDA_ERR_UNSUPPORTED = 3
+# bench.py sets this to a list to collect (event0, event1, flops, dims, ns) per fused launch
+PROFILE = None
 
 
 def _pad32(v):
@@ -78,6 +80,10 @@ class FusedSAMlp:
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
         assert xyz.is_contiguous() and new_xyz.is_contiguous() and idx.is_contiguous()
         assert features is None or (features.is_contiguous() and features.dtype == torch.float32)
+        prof = PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         with torch.cuda.device(xyz.device):
             st = lib.pda_sa_mlp_maxpool(
                 ctypes.c_void_p(xyz.data_ptr()), ctypes.c_void_p(new_xyz.data_ptr()),
@@ -89,6 +95,10 @@ class FusedSAMlp:
             self.unsupported.add(i)
             return None
         _lib.check(st, "pda_sa_mlp_maxpool")
+        if prof is not None:
+            e1.record()
+            d = prep["dims"]
+            prof.append((e0, e1, 2.0 * B * M * ns * (d[0] * d[1] + d[1] * d[2] + d[2] * d[3]), tuple(d), ns))
         return out
 
 
