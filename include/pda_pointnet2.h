@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 4
+#define PDA_POINTNET2_ABI_VERSION 5
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -100,6 +100,16 @@ int pda_group_points(const float *points, const int32_t *idx, float *out, int b,
  * group_points_gpu.cu:14-50): grad_points[b,c,idx[b,p,s]] += grad_out[b,c,p,s]. */
 int pda_group_points_grad(const float *grad_out, const int32_t *idx, float *grad_points, int b,
                           int c, int n, int npoints, int nsample, pda_stream_t stream);
+
+/* MI355X extension (no reference counterpart): gather in the point-major layout,
+ * out[b,e,:] = rows[b, idx[b,e], :] with rows (b,n,c), idx (b,num_idx), out (b,num_idx,c): a
+ * neighbour's features are one contiguous row, so gather and scatter-add are coalesced.  Same
+ * values as pda_group_points on the transposed tensors. */
+int pda_group_rows(const float *rows, const int32_t *idx, float *out, int b, int n, int c,
+                   int64_t num_idx, pda_stream_t stream);
+/* grad_rows[b, idx[b,e], :] += grad_out[b,e,:]; grad_rows (b,n,c) pre-zeroed. */
+int pda_group_rows_grad(const float *grad_out, const int32_t *idx, float *grad_rows, int b, int n,
+                        int c, int64_t num_idx, pda_stream_t stream);
 
 /* ---- three-NN + interpolation ------------------------------------------------------ */
 /* replaces three_nn_wrapper_fast (interpolate.cpp:21-30; kernel interpolate_gpu.cu:16-81).

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -26,6 +26,8 @@ SIGNATURES = {
                              ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int32), _vp],
     "pda_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_group_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_group_rows": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_int64, _vp],
+    "pda_group_rows_grad": [_vp, _vp, _vp, _i, _i, _i, ctypes.c_int64, _vp],
     "pda_three_nn": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pda_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

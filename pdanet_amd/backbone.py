@@ -72,6 +72,45 @@ class IASSD_Backbone(nn.Module):
                     max_translate_range=self.max_translate_range))
             channel_out_list.append(channel_out)
         self.num_point_features = channel_out
+        # MI355X: D-FPS uses one CU per scene and depends on coordinates only, so the leading
+        # D-FPS layers are sampled on a side stream while the main stream runs layer 0.
+        self.prefetch_sampling = True
+        self._side_stream = None
+
+    def _presample(self, xyz):
+        """Sampling of the leading layers that need only coordinates (identity / D-FPS, chained
+        inputs, no given centres), issued on a side stream.  Returns {layer: (event, idx, new_xyz)}."""
+        plan = []
+        for i in range(len(self.SA_modules)):
+            m = self.SA_modules[i]
+            if self.layer_types[i] != 'SA_Layer' or self.ctr_idx_list[i] != -1 or self.layer_inputs[i] != i:
+                break
+            if not pointnet2_modules.coordinate_only_sampling(m.sample_type_list, m.sample_range_list, m.npoint_list):
+                break
+            plan.append(i)
+        if not plan or not xyz.is_cuda:
+            return {}
+        if self._side_stream is None or self._side_stream.device != xyz.device:
+            self._side_stream = torch.cuda.Stream(device=xyz.device)
+        main = torch.cuda.current_stream(xyz.device)
+        side = self._side_stream
+        side.wait_stream(main)
+        out = {}
+        cur = xyz
+        with torch.cuda.stream(side), torch.no_grad():
+            for i in plan:
+                m = self.SA_modules[i]
+                idx = pointnet2_modules.sample_points(cur, None, None, m.sample_type_list, m.sample_range_list,
+                                                      m.npoint_list)
+                new_xyz = pointnet2_modules.pointnet2_utils.gather_operation(
+                    cur.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+                ev = torch.cuda.Event()
+                ev.record(side)
+                for t in (idx, new_xyz):
+                    t.record_stream(main)
+                out[i] = (ev, idx, new_xyz)
+                cur = new_xyz
+        return out
 
     @staticmethod
     def break_up_pc(pc):
@@ -98,13 +137,19 @@ class IASSD_Backbone(nn.Module):
 
         li_cls_pred = None
         sample_list_id = []
+        presampled = self._presample(xyz) if self.prefetch_sampling else {}
         for i in range(len(self.SA_modules)):
             xyz_input = encoder_xyz[self.layer_inputs[i]]
             feature_input = encoder_features[self.layer_inputs[i]]
             if self.layer_types[i] == 'SA_Layer':
                 ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
+                pre = None
+                if i in presampled:
+                    ev, pidx, pxyz = presampled[i]
+                    torch.cuda.current_stream(xyz.device).wait_event(ev)
+                    pre = (pidx, pxyz)
                 li_xyz, li_features, li_cls_pred, sample_list_id = self.SA_modules[i](
-                    xyz_input, feature_input, li_cls_pred, ctr_xyz=ctr_xyz)
+                    xyz_input, feature_input, li_cls_pred, ctr_xyz=ctr_xyz, presampled=pre)
             elif self.layer_types[i] == 'Vote_Layer':
                 li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input)
                 centers = li_xyz

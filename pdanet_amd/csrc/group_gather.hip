@@ -123,3 +123,83 @@ PDA_API int pda_group_points_grad(const float* grad_out, const int32_t* idx, flo
     return pda::launch_rows(true, grad_out, idx, grad_points, b, c, n, (int64_t)npoints * nsample,
                             (hipStream_t)stream, "pda_group_points_grad");
 }
+
+// ---- point-major ("rows") gather: the layout the MI355X pipeline uses internally ------------
+// out[b,e,:] = rows[b, idx[b,e], :]   rows (B,N,C), idx (B,E), out (B,E,C).
+// A neighbour's feature vector is ONE contiguous C*4-byte row, so the gather is a coalesced row
+// copy (16 B per lane) instead of the C scattered 4-byte reads of the channel-major
+// group_points layout, and the gradient is a scatter-add of contiguous rows (the float-atomic
+// shape that runs at full rate, MI355X_MICROARCH.md "Global float atomics").
+// No reference counterpart: the reference only has the (B,C,N) layout (group_points_gpu.cu).
+namespace pda {
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void group_rows_kernel(const float* __restrict__ src,
+                                                          const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int n, int c, int64_t E) {
+    const int bs = blockIdx.y;
+    const int c4 = c >> 2;                                  // float4 per row (c % 4 == 0 path)
+    const int64_t total = E * c4;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int64_t e = o / c4;
+    const int q = (int)(o - e * c4);
+    const int k = idx[(int64_t)bs * E + e];
+    if (!GRAD) {
+        const float4 v = reinterpret_cast<const float4*>(src + ((int64_t)bs * n + k) * c)[q];
+        reinterpret_cast<float4*>(dst + ((int64_t)bs * E + e) * c)[q] = v;
+    } else {
+        const float4 g = reinterpret_cast<const float4*>(src + ((int64_t)bs * E + e) * c)[q];
+        float* d = dst + ((int64_t)bs * n + k) * c + 4 * q;
+        atomicAdd(d + 0, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+    }
+}
+
+template <bool GRAD>
+__global__ __launch_bounds__(256) void group_rows_scalar_kernel(const float* __restrict__ src,
+                                                                 const int32_t* __restrict__ idx,
+                                                                 float* __restrict__ dst, int n, int c, int64_t E) {
+    const int bs = blockIdx.y;
+    const int64_t total = E * c;
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total) return;
+    const int64_t e = o / c;
+    const int q = (int)(o - e * c);
+    const int k = idx[(int64_t)bs * E + e];
+    if (!GRAD) dst[((int64_t)bs * E + e) * c + q] = src[((int64_t)bs * n + k) * c + q];
+    else atomicAdd(dst + ((int64_t)bs * n + k) * c + q, src[((int64_t)bs * E + e) * c + q]);
+}
+
+static int launch_group_rows(bool grad, const float* src, const int32_t* idx, float* dst, int b, int n, int c,
+                             int64_t E, hipStream_t stream, const char* what) {
+    PDA_REQUIRE(b >= 0 && n >= 0 && c >= 0 && E >= 0, "%s: negative size", what);
+    if (b == 0 || c == 0 || E == 0) return PDA_OK;
+    PDA_REQUIRE(src && idx && dst && n > 0, "%s: null pointer or n == 0", what);
+    PDA_REQUIRE(b <= 65535, "%s: b too large", what);
+    const bool vec = (c % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const int64_t total = vec ? E * (c / 4) : E * c;
+    const int64_t gx = divup64(total, 256);
+    PDA_REQUIRE(gx < INT32_MAX, "%s: too many elements", what);
+    dim3 grid((unsigned)gx, b), block(256);
+    if (vec) {
+        if (grad) hipLaunchKernelGGL(group_rows_kernel<true>, grid, block, 0, stream, src, idx, dst, n, c, E);
+        else hipLaunchKernelGGL(group_rows_kernel<false>, grid, block, 0, stream, src, idx, dst, n, c, E);
+    } else {
+        if (grad) hipLaunchKernelGGL(group_rows_scalar_kernel<true>, grid, block, 0, stream, src, idx, dst, n, c, E);
+        else hipLaunchKernelGGL(group_rows_scalar_kernel<false>, grid, block, 0, stream, src, idx, dst, n, c, E);
+    }
+    return check_launch(what);
+}
+
+}  // namespace pda
+
+PDA_API int pda_group_rows(const float* rows, const int32_t* idx, float* out, int b, int n, int c,
+                           int64_t num_idx, pda_stream_t stream) {
+    return pda::launch_group_rows(false, rows, idx, out, b, n, c, num_idx, (hipStream_t)stream, "pda_group_rows");
+}
+
+PDA_API int pda_group_rows_grad(const float* grad_out, const int32_t* idx, float* grad_rows, int b, int n,
+                                int c, int64_t num_idx, pda_stream_t stream) {
+    return pda::launch_group_rows(true, grad_out, idx, grad_rows, b, n, c, num_idx, (hipStream_t)stream,
+                                  "pda_group_rows_grad");
+}

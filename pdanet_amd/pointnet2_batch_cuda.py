@@ -96,6 +96,22 @@ def group_points_grad_wrapper(b, c, n, npoints, nsample, grad_out, idx, grad_poi
     return 1
 
 
+def group_rows(b, n, c, num_idx, rows, idx, out):
+    """MI355X extension: out[b,e,:] = rows[b, idx[b,e], :] (point-major layout)."""
+    _numel_ok(rows, b * n * c, "rows"); _numel_ok(idx, b * num_idx, "idx"); _numel_ok(out, b * num_idx * c, "out")
+    _call("pda_group_rows", rows, _chk(rows, "rows", F32), _chk(idx, "idx", I32), _chk(out, "out", F32),
+          b, n, c, num_idx)
+    return 1
+
+
+def group_rows_grad(b, n, c, num_idx, grad_out, idx, grad_rows):
+    _numel_ok(grad_out, b * num_idx * c, "grad_out"); _numel_ok(idx, b * num_idx, "idx")
+    _numel_ok(grad_rows, b * n * c, "grad_rows")
+    _call("pda_group_rows_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(idx, "idx", I32),
+          _chk(grad_rows, "grad_rows", F32), b, n, c, num_idx)
+    return 1
+
+
 def gather_points_wrapper(b, c, n, npoints, points, idx, out):
     _numel_ok(points, b * c * n, "points"); _numel_ok(idx, b * npoints, "idx")
     _numel_ok(out, b * c * npoints, "out")

@@ -53,6 +53,65 @@ class TransformerEncoderLayerPreNorm(nn.Module):
         return src
 
 
+
+# ---------------------------------------------------------------------------------------------
+# Channel-last ("point-major") execution of the per-group networks.
+#
+# The reference builds every grouped tensor channel-major, (B, C, npoint, nsample), which on the
+# gather side means C scattered 4-byte reads per neighbour and on the dense side a cat + permute
+# + contiguous of the largest tensors of the model before the transformer
+# (pointnet2_modules.py:920-929).  Here grouped tensors are (B, npoint, nsample, C): a neighbour
+# is one contiguous row (pda_group_rows), 1x1 convs are F.linear over the last dim, BatchNorm runs
+# on the SAME element sets through a channels_last NCHW view (identical statistics), and the
+# transformer consumes the tensor batch-first without any relayout.  Same parameters, same
+# state-dict, same math; only summation orders differ.
+CHANNELS_LAST = True
+
+
+def _bn_lastdim(bn, x):
+    """BatchNorm{1,2}d over the last dim of x (B, ..., C): statistics over all other dims, as
+    BatchNorm2d over (B, C, H, W) of the channel-major tensor."""
+    shp = x.shape
+    x4 = x.reshape(shp[0], -1, 1, shp[-1]).permute(0, 3, 1, 2)  # logical (B, C, S, 1), channels_last memory
+    if bn.training and bn.track_running_stats:
+        bn.num_batches_tracked.add_(1)
+    y = F.batch_norm(x4, bn.running_mean, bn.running_var, bn.weight, bn.bias,
+                     bn.training or bn.running_mean is None, bn.momentum, bn.eps)
+    return y.permute(0, 2, 3, 1).reshape(shp)
+
+
+def _mlp_lastdim(layers, x):
+    """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x."""
+    for m in layers:
+        if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+            x = F.linear(x, m.weight.flatten(1), m.bias)
+        elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
+            x = _bn_lastdim(m, x)
+        elif isinstance(m, nn.ReLU):
+            x = F.relu(x)
+        else:
+            raise NotImplementedError(type(m))
+    return x
+
+
+def _transformer_batch_first(tr, x):
+    """TransformerEncoderLayerPreNorm.forward (PointFormer.py:28-38) on x (batch, seq, D) instead of
+    (seq, batch, D), with the module's own parameters; dropout is 0 in PDA-SSD (:632)."""
+    attn = tr.self_attn
+    assert attn.dropout == 0.0 or not tr.training
+    D, H = attn.embed_dim, attn.num_heads
+    src = F.layer_norm(x, (D,), tr.norm1.weight, tr.norm1.bias, tr.norm1.eps)
+    qkv = F.linear(src, attn.in_proj_weight, attn.in_proj_bias)
+    Bn, S, _ = qkv.shape
+    q, k, v = qkv.view(Bn, S, 3, H, D // H).permute(2, 0, 3, 1, 4)  # each (Bn, H, S, hd)
+    a = F.scaled_dot_product_attention(q, k, v)
+    a = a.transpose(1, 2).reshape(Bn, S, D)
+    src = src + F.linear(a, attn.out_proj.weight, attn.out_proj.bias)
+    src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
+    src2 = F.linear(F.relu(F.linear(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)
+    return src + src2
+
+
 def calc_square_dist(a, b):
     """pointnet2_modules.py:19-43: |a|^2 + |b|^2 - 2 a.b  -> (bs, n, m)."""
     a_sq = torch.sum(a * a, dim=-1).unsqueeze(2)
@@ -129,6 +188,13 @@ def sample_points(xyz, features, cls_features, sample_type_list, sample_range_li
     return torch.cat(sampled_idx_list, dim=-1).contiguous()
 
 
+def coordinate_only_sampling(sample_type_list, sample_range_list, npoint_list):
+    """True when a layer's sampling needs nothing but xyz (identity or D-FPS over the whole set)."""
+    kinds = [(t, r, n) for t, r, n in zip(sample_type_list, sample_range_list, npoint_list) if n > 0]
+    return len(kinds) == 1 and kinds[0][1] == -1 and ('D-FPS' in kinds[0][0] or 'DFS' in kinds[0][0]) \
+        and 'cls' not in kinds[0][0] and 'ctr' not in kinds[0][0]
+
+
 def _conv_bn_relu_1d(channels_in, spec):
     layers = []
     for c in spec:
@@ -202,15 +268,19 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
         self.fused = None  # set by fused_ops.enable_fused(): group->MLP->max-pool in one HIP kernel
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
-                new_xyz=None, ctr_xyz=None):
+                new_xyz=None, ctr_xyz=None, presampled=None):
         """xyz (B,N,3), features (B,C,N), cls_features (B,N,num_class) ->
-        new_xyz (B,M,3), new_features (B,C',M), cls_features (B,M,num_class)|None, sampled_idx"""
+        new_xyz (B,M,3), new_features (B,C',M), cls_features (B,M,num_class)|None, sampled_idx.
+        `presampled` = (sampled_idx, new_xyz) computed ahead of time (backbone side stream)."""
         sampled_idx_list = []
         if ctr_xyz is None:
-            sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
-                                             self.sample_range_list, self.npoint_list)
-            xyz_flipped = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
+            if presampled is not None:
+                sampled_idx_list, new_xyz = presampled
+            else:
+                sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
+                                                 self.sample_range_list, self.npoint_list)
+                xyz_flipped = xyz.transpose(1, 2).contiguous()
+                new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
         else:
             new_xyz = ctr_xyz
 
@@ -218,6 +288,9 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
             new_features_list = []
             plain_ball = (not self.dilated_group) and isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup)
             idxs = self._ball_queries(xyz, new_xyz) if plain_ball else [None] * len(self.groupers)
+            use_cl = CHANNELS_LAST and plain_ball and self.pool_method == 'max_pool' and \
+                getattr(self, "channels_last", True) and xyz.is_cuda
+            feats_pm = features.transpose(1, 2).contiguous() if (use_cl and features is not None) else None
             for i in range(len(self.groupers)):
                 if self.fused is not None and plain_ball and self.pool_method == 'max_pool' \
                         and not self.training and not torch.is_grad_enabled():
@@ -225,6 +298,14 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                     if pooled is not None:
                         new_features_list.append(pooled)
                         continue
+                if use_cl and self.groupers[i].use_xyz:
+                    # (B, M, ns, 3 + C): [xyz - centre | features], neighbours gathered as rows
+                    g = pointnet2_utils.group_rows(xyz, idxs[i]) - new_xyz.unsqueeze(2)
+                    if feats_pm is not None:
+                        g = torch.cat([g, pointnet2_utils.group_rows(feats_pm, idxs[i])], dim=-1)
+                    g = _mlp_lastdim(self.mlps[i], g).max(dim=2)[0]          # (B, M, mlp[-1])
+                    new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
+                    continue
                 if plain_ball:
                     new_features = self.groupers[i](xyz, new_xyz, features, idx=idxs[i])
                 else:
@@ -341,22 +422,30 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         _build_heads(self, out_channels, aggregation_mlp, confidence_mlp, num_class, len(self.fin_conv) > 0)
 
     def forward(self, xyz: torch.Tensor, features: torch.Tensor = None, cls_features: torch.Tensor = None,
-                new_xyz=None, ctr_xyz=None):
+                new_xyz=None, ctr_xyz=None, presampled=None):
         sampled_idx_list = []
         if ctr_xyz is None:
-            sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
-                                             self.sample_range_list, self.npoint_list)
-            xyz_flipped = xyz.transpose(1, 2).contiguous()
-            new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
+            if presampled is not None:
+                sampled_idx_list, new_xyz = presampled
+            else:
+                sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
+                                                 self.sample_range_list, self.npoint_list)
+                xyz_flipped = xyz.transpose(1, 2).contiguous()
+                new_xyz = pointnet2_utils.gather_operation(xyz_flipped, sampled_idx_list).transpose(1, 2).contiguous()
             new_xyz_feature = pointnet2_utils.gather_operation(features, sampled_idx_list).transpose(1, 2).contiguous()
         else:
             new_xyz = ctr_xyz  # the reference has no centre features on this branch either (:850-851)
+
+        directional = len(self.groupers) > 0 and isinstance(
+            self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional)
+        if len(self.groupers) > 0 and directional and CHANNELS_LAST and getattr(self, "channels_last", True) \
+                and xyz.is_cuda and self.groupers[0].use_xyz and features is not None:
+            return self._forward_channels_last(xyz, features, new_xyz, new_xyz_feature, sampled_idx_list)
 
         if len(self.groupers) > 0:
             new_features_list = []
             # (B, 3 + C, npoint, 1): the sampled centre's own coordinates and feature (:856)
             global_feature = torch.cat([new_xyz, new_xyz_feature], dim=-1).transpose(1, 2).unsqueeze(dim=-1)
-            directional = isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional)
             idxs = self._ball_queries(xyz, new_xyz) if directional else [None] * len(self.groupers)
             B, npoint = new_xyz.shape[0], new_xyz.shape[1]
             for i in range(len(self.groupers)):
@@ -400,6 +489,46 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         else:
             cls_features = None
         return new_xyz, new_features, cls_features, sampled_idx_list
+
+
+    def _forward_channels_last(self, xyz, features, new_xyz, new_xyz_feature, sampled_idx_list):
+        """The PDA scale loop of forward() in the point-major layout (see CHANNELS_LAST note):
+        grouped tensors are (B, npoint, nsample, C); same parameters and math as the
+        channel-major branch below / the reference (:854-945)."""
+        B, npoint = new_xyz.shape[0], new_xyz.shape[1]
+        idxs = self._ball_queries(xyz, new_xyz)
+        feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
+        global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)
+        centre = new_xyz.unsqueeze(2)                                         # (B, M, 1, 3)
+        outs = []
+        for i in range(len(self.groupers)):
+            r, ns = self.groupers[i].radius, self.nsamples[i]
+            nbr = pointnet2_utils.group_rows(xyz, idxs[i])                    # (B, M, ns, 3) absolute xyz
+            g = pointnet2_utils.group_rows(feats_pm, idxs[i])                 # (B, M, ns, C)
+            diff = nbr - centre
+            # gaussian density exp(-|d|^2 / (2 r^2)) / (2.5 r) and direction d / r (pointnet2_utils.py:594-600)
+            dist = torch.norm(diff, dim=-1, keepdim=True)
+            density = torch.exp(-dist ** 2 / (2 * r ** 2)) / (2.5 * r)        # (B, M, ns, 1)
+            direction = diff / r
+            # DensityNet on density / per-group max (:1000-1003); ReLU after every BN (:973-979)
+            dscale = density / density.max(dim=2, keepdim=True)[0]
+            dn = self.point_density[i].densitynet
+            for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
+                dscale = F.relu(_bn_lastdim(bn, F.linear(dscale, conv.weight.flatten(1), conv.bias)))
+            # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
+            rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
+            rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
+            glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
+            x = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)  # (B, M, ns, 4C)
+            D = x.shape[-1]
+            x = _transformer_batch_first(self.Local_pointformer[i], x.view(B * npoint, ns, D))
+            x = x.max(dim=1)[0].view(B, npoint, D)                            # max over nsample (:931)
+            outs.append(_mlp_lastdim(self.fin_conv[i], x))                    # (B, M, mlp[-1])
+        new_features = torch.cat(outs, dim=-1)                                # (B, M, sum)
+        if self.aggregation_layer is not None:
+            new_features = _mlp_lastdim(self.aggregation_layer, new_features)
+        cls_features = _mlp_lastdim(self.confidence_layers, new_features) if self.confidence_layers is not None else None
+        return new_xyz, new_features.transpose(1, 2).contiguous(), cls_features, sampled_idx_list
 
 
 class Vote_layer(nn.Module):

@@ -165,6 +165,33 @@ class GroupingOperation(Function):
 grouping_operation = GroupingOperation.apply
 
 
+class GroupRows(Function):
+    """MI355X extension: grouping in the point-major layout.  rows (B,N,C), idx (B,...) int32 ->
+    (B, ..., C) with out[b, e, :] = rows[b, idx[b, e], :].  Same values as
+    `grouping_operation(rows^T, idx)` permuted to channel-last; gradient = scatter-add of rows."""
+
+    @staticmethod
+    def forward(ctx, rows: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
+        assert rows.is_contiguous() and idx.is_contiguous()
+        B, N, C = rows.size()
+        E = idx.numel() // B
+        out = torch.empty(tuple(idx.shape) + (C,), dtype=torch.float32, device=rows.device)
+        pointnet2.group_rows(B, N, C, E, rows, idx, out)
+        ctx.for_backwards = (idx, N, C, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        idx, N, C, E = ctx.for_backwards
+        B = idx.shape[0]
+        grad_rows = torch.zeros((B, N, C), dtype=torch.float32, device=grad_out.device)
+        pointnet2.group_rows_grad(B, N, C, E, grad_out.detach().contiguous(), idx, grad_rows)
+        return grad_rows, None
+
+
+group_rows = GroupRows.apply
+
+
 class BallQuery(Function):
     """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
 

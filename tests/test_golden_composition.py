@@ -174,3 +174,37 @@ def test_backbone_vs_reference_composition(mode):
         ref = float(G["bb_%s_feat_%d_absmean" % (mode, li)][0])
         got = float(bd["encoder_features"][li].abs().mean())
         assert abs(got - ref) <= 2e-3 * max(1.0, abs(ref)), (li, got, ref)
+
+
+@gpu
+@pytest.mark.parametrize("cls_name,mlp_key,feat_key", [
+    ("PointnetSAModuleMSG_WithSampling", "sa_mlps", "sa_feats"),
+    ("PointnetSAModuleMSG_WithSampling_Ellipsoid", "pda_mlps", "pda_feats")])
+def test_channels_last_path_equals_channel_major_path(cls_name, mlp_key, feat_key):
+    """The point-major execution (CHANNELS_LAST) against the reference-layout execution of the same
+    module: forward outputs and gradients w.r.t. inputs and parameters, train-mode BN."""
+    xyz = T("sa_xyz", "cuda")
+    outs = {}
+    for cl in (False, True):
+        layer = _sa_layer(cls_name, META[mlp_key]).train()
+        layer.channels_last = cl
+        feats = T(feat_key, "cuda").clone().requires_grad_(True)
+        nx, nf, cf, sidx = layer(xyz, feats, None)
+        (nf.pow(2).mean() + cf.pow(2).mean()).backward()
+        grads = {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}
+        outs[cl] = (nf.detach(), cf.detach(), feats.grad.clone(), grads,
+                    {k: v.clone() for k, v in layer.state_dict().items() if "running" in k})
+    a, b = outs[False], outs[True]
+    close_dense(b[0], a[0].cpu().numpy()); close_dense(b[1], a[1].cpu().numpy())
+    scale = float(a[2].abs().max())
+    assert float((a[2] - b[2]).abs().max()) <= 5e-3 * scale + 1e-7
+    assert set(a[3]) == set(b[3])
+    gmax = max(float(v.abs().max()) for v in a[3].values())
+    for k in a[3]:
+        # weights in front of a BatchNorm have mathematically ~zero gradient along their own
+        # direction: their gradients are round-off sized, so the floor is relative to the largest
+        # gradient of the layer
+        s = float(a[3][k].abs().max())
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-2 * s + 1e-3 * gmax, k
+    for k in a[4]:   # BatchNorm running statistics updated identically
+        assert torch.allclose(a[4][k], b[4][k], rtol=1e-4, atol=1e-5), k

@@ -330,3 +330,24 @@ def test_side_stream_and_graph_capture(ext, oracle):
     g.replay()
     torch.cuda.synchronize()
     assert np.array_equal(idx_o, idx_g.cpu().numpy())
+
+
+# ---------------------------------------------------------------- point-major gather (MI355X extension)
+@pytest.mark.parametrize("b,c,n,m,ns", [(2, 64, 16384, 4096, 32), (2, 3, 4096, 512, 16), (1, 259, 2048, 256, 64),
+                                        (3, 5, 100, 7, 3), (1, 128, 50, 9, 4)])
+def test_group_rows_matches_channel_major_oracle(ext, oracle, b, c, n, m, ns):
+    rng = np.random.default_rng(c + n)
+    pts = rng.normal(size=(b, c, n)).astype(np.float32)                 # channel-major reference layout
+    idx = rng.integers(0, n, size=(b, m, ns)).astype(np.int32)
+    exp = np.zeros((b, c, m, ns), np.float32)
+    oracle.group_points_wrapper(b, c, n, m, ns, pts, idx, exp)
+    rows = dev(np.ascontiguousarray(pts.transpose(0, 2, 1)))            # (b, n, c)
+    out = torch.empty((b, m, ns, c), device="cuda")
+    assert ext.group_rows(b, n, c, m * ns, rows, dev(idx), out) == 1
+    assert np.array_equal(exp.transpose(0, 2, 3, 1), out.cpu().numpy())
+    go = rng.normal(size=(b, c, m, ns)).astype(np.float32)
+    gexp = np.zeros((b, c, n), np.float32)
+    oracle.group_points_grad_wrapper(b, c, n, m, ns, go, idx, gexp)
+    gr = torch.zeros((b, n, c), device="cuda")
+    ext.group_rows_grad(b, n, c, m * ns, dev(np.ascontiguousarray(go.transpose(0, 2, 3, 1))), dev(idx), gr)
+    np.testing.assert_allclose(gr.cpu().numpy(), gexp.transpose(0, 2, 1), rtol=1e-4, atol=1e-4)
