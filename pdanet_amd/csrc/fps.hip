@@ -26,6 +26,8 @@
 // Algorithmic bytes: (m-1)*N*20 + m*4 per scene; compulsory bytes N*16 + m*4.
 #include "pda_common.h"
 
+#include <stdlib.h>
+
 namespace pda {
 
 constexpr int FPS_THREADS = 1024;
@@ -50,7 +52,7 @@ __device__ __forceinline__ int fps_block_argmax(float best, uint32_t T, uint2* s
     const float wmax = wave_max_f32(best);
     const uint32_t wT = wave_min_u32(best == wmax ? T : 0xffffffffu);
     if (lane == 0) slots[w] = make_uint2(__builtin_bit_cast(uint32_t, wmax), wT);
-    __syncthreads();
+    lds_barrier();  // not __syncthreads(): the idx[j] store of the previous round stays in flight
     uint2 s = make_uint2(__builtin_bit_cast(uint32_t, -1.0f), 0xffffffffu);
     if (lane < nwaves) s = slots[lane];
     const float v = __builtin_bit_cast(float, s.x);
@@ -113,6 +115,297 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_reg_kernel(const float* __res
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// fps_pruned_kernel<P>: exact FPS with spatial pruning (2048 <= N <= 16384).
+//
+// The update  temp[k] = min(temp[k], |p_k - s|^2)  changes nothing for points farther from the new
+// sample s than their current temp.  Points arrive shuffled (data_processor.py:93-103), so the
+// kernel first sorts them along a space-filling curve IN LDS (18-bit adaptive Morton key | 14-bit
+// index, bitonic sort) and gives every lane 16 CONSECUTIVE sorted points: a lane owns a compact
+// cluster (box of a few metres), a wave a compact region.  Per round each lane tests the new
+// sample against its cluster's bounding box: when  0.9999 * dist2(box, s) >= max temp of the lane
+// for ALL 64 lanes, the wave skips the 16-point scan and re-publishes its cached candidate.
+// The factor 0.9999 (>> the ~1e-6 relative rounding of the distance expressions) makes the test
+// conservative, so skipped updates are exactly the no-op updates: indices and the final `temp`
+// stay bit-identical to the reference.  Ties are resolved with the same total order as
+// fps_reg_kernel: inside a lane the slots are ordered by the tie-break value T(k) (sorting
+// network at set-up) and scanned with a strict '>', across lanes/waves by (max, min T).
+// The winner's coordinates travel through the LDS slots (no dependent global load per round).
+// Measured (MI355X, 16384->4096, B=2, profiles/r01_fps_variants.txt): 1.85 of 16 waves scan per
+// round on average; 4.74 ms (fps_reg_kernel) -> 3.74 ms.  The round is now bounded by the one
+// scanning wave (~250 dependent-ish instructions alone on its SIMD, 0.60 us) plus two barriers
+// and three LDS round trips (0.31 us).  PDA_FPS_NO_PRUNE=1 selects the unpruned kernel for A/B.
+// readlane(v[js], lstar) for a wave-uniform, run-time slot js: registers cannot be indexed at run
+// time, so descend a binary tree of wave-uniform branches (log2 P levels) to the static slot.
+template <int LO, int N, int P>
+__device__ __forceinline__ void fps_extract(int js, int lstar, const float (&px)[P], const float (&py)[P],
+                                            const float (&pz)[P], const uint32_t (&kT)[P], float& cx, float& cy,
+                                            float& cz, uint32_t& wT) {
+    if constexpr (N == 1) {
+        cx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, px[LO]), lstar));
+        cy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, py[LO]), lstar));
+        cz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, pz[LO]), lstar));
+        wT = (uint32_t)__builtin_amdgcn_readlane((int)kT[LO], lstar);
+    } else {
+        if (js < LO + N / 2) fps_extract<LO, N / 2, P>(js, lstar, px, py, pz, kT, cx, cy, cz, wT);
+        else fps_extract<LO + N / 2, N - N / 2, P>(js, lstar, px, py, pz, kT, cx, cy, cz, wT);
+    }
+}
+
+#ifdef PDA_FPS_STATS
+__device__ unsigned long long g_fps_stats[4];  // [0] wave-scans, [1] wave-rounds, [2] hit lanes
+#endif
+
+template <int P>
+__global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __restrict__ xyz_all,
+                                                                  float* __restrict__ temp_all,
+                                                                  int32_t* __restrict__ idx_all, int n,
+                                                                  int m, int L) {
+    constexpr int NS = FPS_THREADS * P;  // sort size (power of two)
+    __shared__ uint32_t skey[NS];
+    __shared__ float red[FPS_WAVES * 6];
+    __shared__ uint2 slots[2][FPS_WAVES];
+    __shared__ float4 cand[2][FPS_WAVES];
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int w = wave_id();
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
+    int32_t* __restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const float INF = __builtin_inff();
+
+    // ---- 1. scene bounding box ---------------------------------------------------------
+    float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + i * FPS_THREADS;
+        if (k < n) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const float v = xyz[k * 3 + a];
+                lo[a] = fminf(lo[a], v); hi[a] = fmaxf(hi[a], v);
+            }
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float mn = -wave_max_f32(-lo[a]);
+        const float mx = wave_max_f32(hi[a]);
+        if (lane == 0) { red[w * 6 + a] = mn; red[w * 6 + 3 + a] = mx; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        float mn = INF, mx = -INF;
+        for (int q = 0; q < FPS_WAVES; ++q) { mn = fminf(mn, red[q * 6 + a]); mx = fmaxf(mx, red[q * 6 + 3 + a]); }
+        lo[a] = mn; hi[a] = mx;
+    }
+    // ---- 2. adaptive 18-bit key: each level splits the axis whose cells are currently widest
+    int bits[3] = {0, 0, 0};
+    uint64_t seq = 0;  // 2 bits per level: which axis
+    {
+        float cell[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+        for (int sidx = 0; sidx < 18; ++sidx) {
+            const int a = (cell[0] >= cell[1] && cell[0] >= cell[2]) ? 0 : (cell[1] >= cell[2] ? 1 : 2);
+            seq |= (uint64_t)a << (2 * sidx);
+            if (a == 0) { bits[0]++; cell[0] *= 0.5f; } else if (a == 1) { bits[1]++; cell[1] *= 0.5f; } else { bits[2]++; cell[2] *= 0.5f; }
+        }
+    }
+    float scl[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float ext = hi[a] - lo[a];
+        scl[a] = ext > 0.f ? (float)(1 << bits[a]) / (ext * 1.0001f) : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = t + i * FPS_THREADS;
+        uint32_t key = 0xffffffffu;  // padding sorts to the end
+        if (k < n) {
+            uint32_t q[3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const int qq = (int)((xyz[k * 3 + a] - lo[a]) * scl[a]);
+                q[a] = (uint32_t)min(max(qq, 0), (1 << bits[a]) - 1);
+            }
+            int rem0 = bits[0], rem1 = bits[1], rem2 = bits[2];
+            uint32_t code = 0;
+            for (int sidx = 0; sidx < 18; ++sidx) {
+                const int a = (int)((seq >> (2 * sidx)) & 3);
+                uint32_t bit;
+                if (a == 0) { rem0--; bit = (q[0] >> rem0) & 1u; }
+                else if (a == 1) { rem1--; bit = (q[1] >> rem1) & 1u; }
+                else { rem2--; bit = (q[2] >> rem2) & 1u; }
+                code = (code << 1) | bit;
+            }
+            key = (code << 14) | (uint32_t)k;
+        }
+        skey[k] = key;
+    }
+    __syncthreads();
+    // ---- 3. bitonic sort of skey[0, NS) in LDS -----------------------------------------------
+    for (int kk2 = 2; kk2 <= NS; kk2 <<= 1) {
+        for (int jj = kk2 >> 1; jj > 0; jj >>= 1) {
+            for (int e = t; e < NS / 2; e += FPS_THREADS) {
+                const int i0 = ((e & ~(jj - 1)) << 1) | (e & (jj - 1));
+                const int i1 = i0 | jj;
+                const uint32_t a = skey[i0], b = skey[i1];
+                const bool asc = (i0 & kk2) == 0;
+                if ((a > b) == asc) { skey[i0] = b; skey[i1] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    // ---- 4. my P consecutive sorted points, ordered by tie-break value inside the lane ------
+    uint32_t kT[P];   // tie-break value (0xffffffff = empty slot)
+    int kk[P];
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const uint32_t e = skey[t * P + i];
+        const bool valid = e != 0xffffffffu;
+        kk[i] = valid ? (int)(e & 0x3fffu) : -1;
+        kT[i] = valid ? fps_tiebreak((uint32_t)kk[i], L) : 0xffffffffu;
+    }
+#pragma unroll
+    for (int k2 = 2; k2 <= P; k2 <<= 1)
+#pragma unroll
+        for (int j2 = k2 >> 1; j2 > 0; j2 >>= 1)
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const int l2 = i ^ j2;
+                if (l2 > i) {
+                    const bool asc = (i & k2) == 0;
+                    const bool sw = (kT[i] > kT[l2]) == asc;
+                    const uint32_t ta = kT[i], tb = kT[l2];
+                    const int ka = kk[i], kb = kk[l2];
+                    kT[i] = sw ? tb : ta; kT[l2] = sw ? ta : tb;
+                    kk[i] = sw ? kb : ka; kk[l2] = sw ? ka : kb;
+                }
+            }
+    float px[P], py[P], pz[P], tp[P];
+    float blo[3] = {INF, INF, INF}, bhi[3] = {-INF, -INF, -INF};
+    float lbest = -1.f;
+    int bi = 0;
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        if (kk[i] >= 0) {
+            px[i] = xyz[kk[i] * 3 + 0]; py[i] = xyz[kk[i] * 3 + 1]; pz[i] = xyz[kk[i] * 3 + 2];
+            tp[i] = temp[kk[i]];
+            blo[0] = fminf(blo[0], px[i]); bhi[0] = fmaxf(bhi[0], px[i]);
+            blo[1] = fminf(blo[1], py[i]); bhi[1] = fmaxf(bhi[1], py[i]);
+            blo[2] = fminf(blo[2], pz[i]); bhi[2] = fmaxf(bhi[2], pz[i]);
+        } else {
+            px[i] = py[i] = pz[i] = 0.f;
+            tp[i] = -1.f;
+        }
+        const bool g = tp[i] > lbest;
+        bi = g ? i : bi;
+        lbest = g ? tp[i] : lbest;
+    }
+
+    // wave candidate cache (wave-uniform values)
+    float wmax = -1.f, cx = 0.f, cy = 0.f, cz = 0.f;
+    uint32_t wT = 0xffffffffu;
+    bool dirty = true;  // no cached candidate yet
+    bool publish = false;
+
+    int old = 0;
+    if (t == 0) idx[0] = 0;
+    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    for (int j = 1; j < m; ++j) {
+        // ---- conservative box test of my cluster against the new sample ----------------
+        const float ex = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.f);
+        const float ey = fmaxf(fmaxf(blo[1] - y1, y1 - bhi[1]), 0.f);
+        const float ez = fmaxf(fmaxf(blo[2] - z1, z1 - bhi[2]), 0.f);
+        const float dbox = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+        const bool hit = dbox * 0.9999f < lbest;
+#ifdef PDA_FPS_STATS
+        if (lane == 0) atomicAdd(&g_fps_stats[1], 1ull);
+#endif
+        if (dirty || __ballot(hit) != 0ull) {
+#ifdef PDA_FPS_STATS
+            if (lane == 0) { atomicAdd(&g_fps_stats[0], 1ull); atomicAdd(&g_fps_stats[2], (unsigned long long)__builtin_popcountll(__ballot(hit))); }
+#endif
+            // all P updates are independent; the arg-max is a tree (depth log2 P) that keeps the
+            // LOWER slot on equal values (slots are in tie-break order) -- a serial chain of
+            // compare/select would expose ~2 x P dependent VALU latencies on this lone wave
+            float bv[P];
+            int bx[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) {
+                const float d = sqdist3(px[i], py[i], pz[i], x1, y1, z1);  // (x2 - x1), :133
+                tp[i] = fminf(d, tp[i]);
+                bv[i] = tp[i];
+                bx[i] = i;
+            }
+#pragma unroll
+            for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+                for (int i = 0; i + st < P; i += 2 * st) {
+                    const bool g = bv[i + st] > bv[i];  // strict: lower slot wins ties
+                    bx[i] = g ? bx[i + st] : bx[i];
+                    bv[i] = fmaxf(bv[i], bv[i + st]);
+                }
+            const float best = bv[0];
+            const int b2 = bx[0];
+            lbest = best; bi = b2;
+            // wave candidate: max value, ties by tie-break value
+            wmax = wave_max_f32(lbest);
+            const unsigned long long eq = __ballot(lbest == wmax);
+            int lstar;
+            if (__builtin_popcountll(eq) == 1) {
+                lstar = (int)__builtin_ctzll(eq);
+            } else {
+                uint32_t myT = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < P; ++i) myT = (bi == i) ? kT[i] : myT;
+                const uint32_t tmin = wave_min_u32(lbest == wmax ? myT : 0xffffffffu);
+                const unsigned long long eq2 = __ballot(lbest == wmax && myT == tmin);
+                lstar = (int)__builtin_ctzll(eq2 | (1ull << 63));
+            }
+            lstar = __builtin_amdgcn_readfirstlane(lstar);
+            const int js = __builtin_amdgcn_readlane(bi, lstar);
+            fps_extract<0, P>(js, lstar, px, py, pz, kT, cx, cy, cz, wT);  // wave-uniform binary tree
+            dirty = false;
+            publish = true;
+        }
+        // ---- publish (only waves whose candidate changed), reduce in ONE wave, broadcast --------
+        // Waves that skipped the scan have nothing new to say: their slot persists.  The 16-slot
+        // reduction runs in wave 0 only and the winner goes through a 16-byte LDS record; the
+        // other waves sleep at the barriers instead of issuing ~45 redundant instructions each
+        // (4 waves share a SIMD: the redundant reductions were stealing issue slots from the one
+        // wave that is actually scanning).
+        if (publish && lane == 0) {
+            slots[0][w] = make_uint2(__builtin_bit_cast(uint32_t, wmax), wT);
+            cand[0][w] = make_float4(cx, cy, cz, 0.f);
+        }
+        publish = false;
+        lds_barrier();
+        if (w == 0) {
+            uint2 sv = make_uint2(__builtin_bit_cast(uint32_t, -1.0f), 0xffffffffu);
+            float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lane < FPS_WAVES) { sv = slots[0][lane]; c4 = cand[0][lane]; }
+            const float v = __builtin_bit_cast(float, sv.x);
+            const float bmax = row0_max_f32(v);
+            const uint32_t bTw = row0_min_u32(v == bmax ? sv.y : 0xffffffffu);
+            // exactly one slot holds (bmax, bT): that lane forwards its record
+            if (lane < FPS_WAVES && v == bmax && sv.y == bTw)
+                cand[1][0] = make_float4(c4.x, c4.y, c4.z, __builtin_bit_cast(float, bTw));
+        }
+        lds_barrier();
+        const float4 win = cand[1][0];
+        x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.x)));
+        y1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.y)));
+        z1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.z)));
+        const uint32_t bT = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.w));
+        old = (int)fps_tiebreak_decode(bT, L);
+        if (t == 0) idx[j] = old;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (kk[i] >= 0) temp[kk[i]] = tp[i];
+}
+
 template <bool WITH_DIST>
 __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __restrict__ data_all,
                                                                   float* __restrict__ temp_all,
@@ -172,6 +465,14 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
         return check_launch(what);
     }
     const int P = divup(n, FPS_THREADS);
+    static const int no_prune = getenv("PDA_FPS_NO_PRUNE") ? atoi(getenv("PDA_FPS_NO_PRUNE")) : 0;
+    if (!no_prune && n >= 2048 && n <= 16384 && m > 2) {
+        if (P <= 2) hipLaunchKernelGGL(fps_pruned_kernel<2>, grid, block, 0, stream, data, temp, idx, n, m, L);
+        else if (P <= 4) hipLaunchKernelGGL(fps_pruned_kernel<4>, grid, block, 0, stream, data, temp, idx, n, m, L);
+        else if (P <= 8) hipLaunchKernelGGL(fps_pruned_kernel<8>, grid, block, 0, stream, data, temp, idx, n, m, L);
+        else hipLaunchKernelGGL(fps_pruned_kernel<16>, grid, block, 0, stream, data, temp, idx, n, m, L);
+        return check_launch(what);
+    }
 #define PDA_FPS_CASE(PP)                                                                          \
     hipLaunchKernelGGL(fps_reg_kernel<PP>, grid, block, 0, stream, data, temp, idx, n, m, L)
     if (P <= 1) PDA_FPS_CASE(1);
@@ -186,6 +487,14 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
 }
 
 }  // namespace pda
+
+#ifdef PDA_FPS_STATS
+PDA_API int pda_debug_fps_stats(unsigned long long* out, int reset) {
+    hipMemcpyFromSymbol(out, HIP_SYMBOL(pda::g_fps_stats), sizeof(unsigned long long) * 4);
+    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(pda::g_fps_stats), z, sizeof(z)); }
+    return 0;
+}
+#endif
 
 PDA_API int pda_opt_n_threads(int work_size) {
     // cuda_utils.h:10-14: pow_2 = log(double(n)) / log(2.0) truncated; clamp(1 << pow_2, 1, 1024).

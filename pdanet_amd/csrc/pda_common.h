@@ -82,6 +82,13 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return (T*)(((uint64_t)hi << 32) | lo);
 }
 
+// Workgroup barrier that orders LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier).  Unlike
+// __syncthreads() it does NOT wait for outstanding global stores/loads (vmcnt), so a result store
+// issued in a latency-critical loop (FPS writes idx[j] every round) stays in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Wave-wide reductions of idempotent ops with the DPP modifier fused into the ALU op
 // (gfx9 DPP: row_shr:n inside rows of 16 lanes, then row_bcast:15 / row_bcast:31 across
 // rows).  A lane whose DPP source is out of range keeps its own value.  `s_nop 1` covers
