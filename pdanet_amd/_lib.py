@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpda_pointnet2.so")
+# PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
 ABI_VERSION = 5
 
 _vp = ctypes.c_void_p

@@ -20,6 +20,8 @@
 // the kernel is VALU-bound (M*N distance tests), see DESIGN.md.
 #include "pda_common.h"
 
+#include <algorithm>
+
 namespace pda {
 
 constexpr int BQ_BATCH = 8;
@@ -37,9 +39,12 @@ struct BqParams {
     int n, m, seglen;
 };
 
-template <int NR, bool DILATED>
-__global__ __launch_bounds__(512) void ball_query_kernel(const BqParams p) {
+// RowT: element type of the partial rows in LDS.  uint16_t (index relative to the segment start)
+// whenever a segment has < 65536 points: halves the LDS per wave, i.e. doubles the waves a CU holds.
+template <int NR, bool DILATED, typename RowT>
+__global__ __launch_bounds__(1024) void ball_query_kernel(const BqParams p) {
     extern __shared__ int32_t lds[];
+    RowT* const rows = reinterpret_cast<RowT*>(lds);   // rows first, int32 counts after (lds_cnt_off)
     const int w = wave_id();
     const int lane = lane_id();
     const int S = (int)(blockDim.x >> 6);
@@ -106,16 +111,16 @@ __global__ __launch_bounds__(512) void ball_query_kernel(const BqParams p) {
             if (DILATED) {
                 // ball_query_gpu.cu:96-115: d2 == 0 appends, then the shell test appends
                 const bool t0 = in_seg && (d2[u] == 0.f) && cnt[0] < p.ns[0];
-                lds[t0 ? row[0] + cnt[0] : row[0] + p.ns[0]] = k;
+                rows[t0 ? row[0] + cnt[0] : row[0] + p.ns[0]] = (RowT)(k - k_begin);
                 cnt[0] += t0 ? 1 : 0;
                 const bool t1 = in_seg && (d2[u] >= p.r2min) && (d2[u] < p.r2[0]) && cnt[0] < p.ns[0];
-                lds[t1 ? row[0] + cnt[0] : row[0] + p.ns[0]] = k;
+                rows[t1 ? row[0] + cnt[0] : row[0] + p.ns[0]] = (RowT)(k - k_begin);
                 cnt[0] += t1 ? 1 : 0;
             } else {
 #pragma unroll
                 for (int i = 0; i < NR; ++i) {
                     const bool t = in_seg && (d2[u] < p.r2[i]) && cnt[i] < p.ns[i];
-                    lds[t ? row[i] + cnt[i] : row[i] + p.ns[i]] = k;  // slot ns = per-lane dummy
+                    rows[t ? row[i] + cnt[i] : row[i] + p.ns[i]] = (RowT)(k - k_begin);  // slot ns = per-lane dummy
                     cnt[i] += t ? 1 : 0;
                 }
             }
@@ -144,8 +149,8 @@ __global__ __launch_bounds__(512) void ball_query_kernel(const BqParams p) {
             for (int s = 0; s < S; ++s) {
                 const int cs = lds[p.lds_cnt_off[i] + s * PDA_WAVE + cc];
                 const int base = p.lds_row_off[i] + (s * PDA_WAVE + cc) * rs;
-                if (first < 0 && cs > 0) first = lds[base];
-                if (val < 0 && off < cs) val = lds[base + off];
+                if (first < 0 && cs > 0) first = (int)rows[base] + s * p.seglen;
+                if (val < 0 && off < cs) val = (int)rows[base + off] + s * p.seglen;
                 off -= cs;
             }
             if (first >= 0) out[e] = val >= 0 ? val : first;
@@ -170,35 +175,55 @@ static int launch_ball_query(const float* new_xyz, const float* xyz, int32_t* co
     PDA_REQUIRE((int64_t)b * n * 3 < INT32_MAX && (int64_t)b * m * 64 < INT32_MAX,
                 "%s: problem too large for 32-bit indexing", what);
 
-    // S waves per 64-centre tile: enough waves to cover the chip (256 CUs x ~8), at least 512
-    // points per segment, LDS per workgroup <= 64 KiB where possible.
+    // S waves (= point segments) per 64-centre tile.  Pick the S that keeps the most waves in
+    // flight: total waves = tiles*b*S, but a CU holds only floor(160 KiB / LDS per workgroup)
+    // workgroups and 32 waves.  Segments shorter than 128 points are not worth a wave.
+    // (Measured: at ONCE layer 1 -- 64 tiles x 2 scenes -- S = 2 left one wave per CU and the
+    // 4096-centre query took as long as the 16384-centre one.)
     const int tiles = divup(m, PDA_WAVE);
     int S = 1;
-    while (S < 8 && (int64_t)tiles * b * S < 2048 && divup(n, S * 2) >= 512 &&
-           (int64_t)(S * 2) * PDA_WAVE * sum_rs * 4 <= 64 * 1024)
-        S *= 2;
-    const size_t lds_bytes = (size_t)S * PDA_WAVE * sum_rs * 4;
+    int64_t best_eff = 0;
+    for (int cand = 1; cand <= 16; cand *= 2) {
+        const int64_t rb = divup(n, cand) + BQ_BATCH <= 65535 ? 2 : 4;
+        const int64_t lds = (int64_t)cand * PDA_WAVE * ((sum_rs - nr) * rb + nr * 4) + 16;
+        if (lds > 150 * 1024) break;
+        if (cand > 1 && divup(n, cand) < 128) break;
+        const int64_t per_cu = std::min<int64_t>(160 * 1024 / lds, 32 / cand) * cand;
+        const int64_t eff = std::min<int64_t>((int64_t)tiles * b * cand, 256 * per_cu);
+        if (eff > best_eff) { best_eff = eff; S = cand; }
+    }
+    BqParams p{};
+    p.new_xyz = new_xyz; p.xyz = xyz; p.n = n; p.m = m; p.r2min = r2min;
+    p.seglen = divup(divup(n, S), BQ_BATCH) * BQ_BATCH;
+    const bool idx16 = p.seglen <= 65535;
+    const size_t row_bytes = idx16 ? 2 : 4;
+    int off = 0;  // in row elements
+    for (int i = 0; i < nr; ++i) {
+        p.idx[i] = idx[i]; p.r2[i] = r2[i]; p.ns[i] = nsamples[i];
+        p.lds_row_off[i] = off; off += S * PDA_WAVE * (nsamples[i] + 1);
+    }
+    const size_t rows_bytes = ((size_t)off * row_bytes + 15) / 16 * 16;
+    int coff = (int)(rows_bytes / 4);  // counts: int32 units
+    for (int i = 0; i < nr; ++i) { p.lds_cnt_off[i] = coff; coff += S * PDA_WAVE; }
+    const size_t lds_bytes = (size_t)coff * 4;
     if (lds_bytes > 160 * 1024) {
         set_error("%s: nsample total %d needs %zu B of LDS (> 160 KiB)", what, sum_rs, lds_bytes);
         return PDA_ERR_UNSUPPORTED;
     }
 
-    BqParams p{};
-    p.new_xyz = new_xyz; p.xyz = xyz; p.n = n; p.m = m; p.r2min = r2min;
-    p.seglen = divup(divup(n, S), BQ_BATCH) * BQ_BATCH;
-    int off = 0;
-    for (int i = 0; i < nr; ++i) {
-        p.idx[i] = idx[i]; p.r2[i] = r2[i]; p.ns[i] = nsamples[i];
-        p.lds_row_off[i] = off; off += S * PDA_WAVE * (nsamples[i] + 1);
-    }
-    for (int i = 0; i < nr; ++i) { p.lds_cnt_off[i] = off; off += S * PDA_WAVE; }
-
     dim3 grid(tiles, b), block(S * PDA_WAVE);
     void (*kern)(const BqParams) = nullptr;
-    if (dilated) kern = ball_query_kernel<1, true>;
-    else if (nr == 1) kern = ball_query_kernel<1, false>;
-    else if (nr == 2) kern = ball_query_kernel<2, false>;
-    else kern = ball_query_kernel<3, false>;
+    if (idx16) {
+        if (dilated) kern = ball_query_kernel<1, true, uint16_t>;
+        else if (nr == 1) kern = ball_query_kernel<1, false, uint16_t>;
+        else if (nr == 2) kern = ball_query_kernel<2, false, uint16_t>;
+        else kern = ball_query_kernel<3, false, uint16_t>;
+    } else {
+        if (dilated) kern = ball_query_kernel<1, true, int32_t>;
+        else if (nr == 1) kern = ball_query_kernel<1, false, int32_t>;
+        else if (nr == 2) kern = ball_query_kernel<2, false, int32_t>;
+        else kern = ball_query_kernel<3, false, int32_t>;
+    }
     if (lds_bytes > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)lds_bytes);
