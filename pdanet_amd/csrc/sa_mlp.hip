@@ -83,25 +83,55 @@ struct SaMlpParams {
 template <int KS, int R, int CH, typename HinT>
 __device__ __forceinline__ void gemm_chunk(f32x16 (&acc)[CH], const HinT& hin, const float* __restrict__ wf,
                                             int rb0, int lane) {
+    // One "step" = U float4 fragment loads per row block = 4*U k-steps = CH*4*U >= 16 MFMAs
+    // (>= 1024 cycles).  The fragments of step s+1 are requested BEFORE the MFMAs of step s and a
+    // sched_barrier keeps hipcc from sinking the loads back next to their use: with one wave per
+    // SIMD nothing else hides the L2 latency of the weight stream (without this the MFMA pipe
+    // waited ~1/3 of the time on s_waitcnt vmcnt, profiles/r01_sa_mlp_fused_microbench.txt).
+    constexpr int U = CH >= 4 ? 1 : (CH == 2 ? 2 : 4);
+    constexpr int TQ = KS / 4;
+    constexpr int STEPS = (TQ + U - 1) / U;
 #pragma unroll
     for (int r = 0; r < CH; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    float4 cur[CH][U], nxt[CH][U];
+    auto load = [&](float4 (&dst)[CH][U], int step) {
 #pragma unroll
-    for (int tq = 0; tq < KS / 4; ++tq) {
-        float4 a[CH];
-#pragma unroll
-        for (int r = 0; r < CH; ++r)
-            a[r] = *reinterpret_cast<const float4*>(wf + ((size_t)(tq * R + rb0 + r) * 64 + lane) * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float b = hin(tq * 4 + e);
+        for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
-                const float av = e == 0 ? a[r].x : (e == 1 ? a[r].y : (e == 2 ? a[r].z : a[r].w));
-                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
+                const int tq = step * U + u;
+                if (tq < TQ)
+                    dst[r][u] = *reinterpret_cast<const float4*>(wf + ((size_t)(tq * R + rb0 + r) * 64 + lane) * 4);
+            }
+    };
+    load(cur, 0);
+#pragma unroll
+    for (int step = 0; step < STEPS; ++step) {
+        if (step + 1 < STEPS) load(nxt, step + 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int tq = step * U + u;
+            if (tq < TQ) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float b = hin(tq * 4 + e);
+#pragma unroll
+                    for (int r = 0; r < CH; ++r) {
+                        const float4 a4 = cur[r][u];
+                        const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                        acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
+                    }
+                }
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < CH; ++r) cur[r][u] = nxt[r][u];
     }
 }
 
