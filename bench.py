@@ -197,13 +197,13 @@ def main():
         alg_bytes = fps_algorithmic_bytes(n, m) * args.batch
         achieved = alg_bytes / fps_avg_s / 1e9 if fps_avg_s > 0 else 0.0
         roof = {
-            "kernel": "fps_reg_kernel (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
+            "kernel": "fps_pruned_kernel (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("pda::fps_reg_kernel") if (n, m, args.batch) == (16384, 4096, 2) else None,
+            "traffic": pmc_traffic("pda::fps_pruned_kernel") if (n, m, args.batch) == (16384, 4096, 2) else None,
             "avg_launch_ms": fps_avg_s * 1e3,
             "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene) / kernel time; the kernel keeps "
-                    "the scene in registers, so real HBM traffic is the compulsory N*16+m*4 bytes; traffic = "
+                    "the scene in registers (exact spatial pruning skips no-op updates), so real HBM traffic is the compulsory N*16+m*4 bytes; traffic = "
                     "(2*FETCH_SIZE+WRITE_SIZE) KB per launch from profiles/r01_pmc (separate rocprofv3 --pmc passes)",
         }
 

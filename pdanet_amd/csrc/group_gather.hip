@@ -176,7 +176,10 @@ static int launch_group_rows(bool grad, const float* src, const int32_t* idx, fl
     if (b == 0 || c == 0 || E == 0) return PDA_OK;
     PDA_REQUIRE(src && idx && dst && n > 0, "%s: null pointer or n == 0", what);
     PDA_REQUIRE(b <= 65535, "%s: b too large", what);
-    const bool vec = (c % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    // gradients: one float per lane, so a wave-instruction adds 256 CONTIGUOUS bytes of one or two
+    // rows -- the shape float atomics run at full rate in (MI355X_MICROARCH.md); the float4 mapping
+    // spreads one atomic instruction over 16-byte-strided words of 4 rows and measured 4x slower
+    const bool vec = !grad && (c % 4 == 0) && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
     const int64_t total = vec ? E * (c / 4) : E * c;
     const int64_t gx = divup64(total, 256);
     PDA_REQUIRE(gx < INT32_MAX, "%s: too many elements", what);

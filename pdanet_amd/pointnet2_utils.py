@@ -17,11 +17,17 @@ from torch.autograd import Function
 
 from . import pointnet2_batch_cuda as pointnet2
 
+# Under torch.autocast the dense layers may run in bf16; the point operators always compute in
+# fp32 ("ops stay fp32"): inputs are cast back at the operator boundary.
+_fwd = torch.amp.custom_fwd(device_type="cuda", cast_inputs=torch.float32)
+_bwd = torch.amp.custom_bwd(device_type="cuda")
+
 
 class FarthestPointSampling(Function):
     """pointnet2_utils.py:10-33.  xyz (B,N,3) -> idx (B,npoint) int32; temp pre-filled 1e10."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         assert xyz.is_contiguous()
         B, N, _ = xyz.size()
@@ -43,6 +49,7 @@ class FurthestPointSamplingWithDist(Function):
     """pointnet2_utils.py:39-62.  dist matrix (B,N,N) -> idx (B,npoint)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, xyz: torch.Tensor, npoint: int) -> torch.Tensor:
         assert xyz.is_contiguous()
         B, N, _ = xyz.size()
@@ -64,6 +71,7 @@ class GatherOperation(Function):
     """pointnet2_utils.py:67-98.  features (B,C,N), idx (B,npoint) -> (B,C,npoint)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         assert features.is_contiguous()
         assert idx.is_contiguous()
@@ -75,6 +83,7 @@ class GatherOperation(Function):
         return output
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         idx, C, N = ctx.for_backwards
         B, npoint = idx.size()
@@ -91,6 +100,7 @@ class ThreeNN(Function):
     """pointnet2_utils.py:104-130.  Returns (sqrt(dist2), idx), both (B,N,3)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, unknown: torch.Tensor, known: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         assert unknown.is_contiguous()
         assert known.is_contiguous()
@@ -114,6 +124,7 @@ class ThreeInterpolate(Function):
     """pointnet2_utils.py:136-178.  features (B,C,M), idx/weight (B,n,3) -> (B,C,n)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
         assert features.is_contiguous()
         assert idx.is_contiguous()
@@ -126,6 +137,7 @@ class ThreeInterpolate(Function):
         return output
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out: torch.Tensor):
         idx, weight, m = ctx.three_interpolate_for_backward
         B, c, n = grad_out.size()
@@ -142,6 +154,7 @@ class GroupingOperation(Function):
     """pointnet2_utils.py:184-222.  features (B,C,N), idx (B,npoint,nsample) -> (B,C,npoint,nsample)."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, features: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         assert features.is_contiguous()
         assert idx.is_contiguous()
@@ -153,6 +166,7 @@ class GroupingOperation(Function):
         return output
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out: torch.Tensor):
         idx, N = ctx.for_backwards
         B, C, npoint, nsample = grad_out.size()
@@ -171,6 +185,7 @@ class GroupRows(Function):
     `grouping_operation(rows^T, idx)` permuted to channel-last; gradient = scatter-add of rows."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, rows: torch.Tensor, idx: torch.Tensor) -> torch.Tensor:
         assert rows.is_contiguous() and idx.is_contiguous()
         B, N, C = rows.size()
@@ -181,6 +196,7 @@ class GroupRows(Function):
         return out
 
     @staticmethod
+    @_bwd
     def backward(ctx, grad_out):
         idx, N, C, E = ctx.for_backwards
         B = idx.shape[0]
@@ -196,6 +212,7 @@ class BallQuery(Function):
     """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, radius: float, nsample: int, xyz: torch.Tensor, new_xyz: torch.Tensor) -> torch.Tensor:
         assert new_xyz.is_contiguous()
         assert xyz.is_contiguous()
@@ -218,6 +235,7 @@ class BallQueryDilated(Function):
     """pointnet2_utils.py:258-284."""
 
     @staticmethod
+    @_fwd
     def forward(ctx, max_radius: float, min_radius: float, nsample: int, xyz: torch.Tensor,
                 new_xyz: torch.Tensor) -> torch.Tensor:
         assert new_xyz.is_contiguous()

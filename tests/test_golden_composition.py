@@ -208,3 +208,23 @@ def test_channels_last_path_equals_channel_major_path(cls_name, mlp_key, feat_ke
         assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-2 * s + 1e-3 * gmax, k
     for k in a[4]:   # BatchNorm running statistics updated identically
         assert torch.allclose(a[4][k], b[4][k], rtol=1e-4, atol=1e-5), k
+
+
+@gpu
+def test_kitti_backbone_forward_backward_runs():
+    """The KITTI yaml (4096/1024/512/256 centres, layer 5 with a 1024-wide chain): forward +
+    backward on a synthetic 16384-pt KITTI batch; shapes as the head expects, finite gradients."""
+    from pdanet_amd import synth
+    from pdanet_amd.backbone import build_backbone
+    model, cfg = build_backbone("kitti_pda_ssd.yaml")
+    model = fill_deterministic(model).cuda().train()
+    pts = torch.from_numpy(synth.batch_points(2, 16384, config_id=3, dist="L", dataset="kitti")).cuda()
+    bd = model({"batch_size": 2, "points": pts})
+    assert bd["centers"].shape == (2 * 256, 4) and bd["centers_features"].shape == (2 * 256, 512)
+    assert [t.shape[1] for t in bd["encoder_xyz"]] == [16384, 4096, 1024, 512, 256, 256, 256]
+    assert bd["sa_ins_preds"][1].shape == (2, 1024, 1 + 3) and bd["sa_ins_preds"][2].shape == (2, 512, 1 + 3)
+    loss = bd["centers_features"].pow(2).mean() + bd["ctr_offsets"][:, 1:].pow(2).mean()
+    loss.backward()
+    n_grad = sum(1 for p in model.parameters() if p.grad is not None)
+    assert n_grad >= 0.9 * sum(1 for _ in model.parameters())
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)

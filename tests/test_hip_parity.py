@@ -351,3 +351,32 @@ def test_group_rows_matches_channel_major_oracle(ext, oracle, b, c, n, m, ns):
     gr = torch.zeros((b, n, c), device="cuda")
     ext.group_rows_grad(b, n, c, m * ns, dev(np.ascontiguousarray(go.transpose(0, 2, 3, 1))), dev(idx), gr)
     np.testing.assert_allclose(gr.cpu().numpy(), gexp.transpose(0, 2, 1), rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------- BASELINE config 5 sizes (65536-pt scenes)
+def test_config5_sizes_fps_and_ball_query(ext, oracle):
+    """Dense 65536-pt ONCE scene: FPS 65536 -> 16384 (streaming kernel, n > 24576) and the
+    16384 x 65536 ball queries of layer 0, against the oracle directly plus the size-independent
+    properties (distinct indices, non-increasing selection distance, ascending neighbour lists)."""
+    b, n, m = 1, 65536, 16384
+    xyz = cloud(b, n, seed=5)
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+    assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    sel = idx_d[0]
+    assert len(set(sel.tolist())) == m                     # a point is never picked twice
+    # distance of pick j to the set of earlier picks never increases (FPS invariant), checked on a prefix
+    p = xyz[0][sel[:512]].astype(np.float64)
+    d = ((p[:, None] - p[None]) ** 2).sum(-1)
+    mind = np.array([d[j, :j].min() for j in range(1, 512)])
+    assert (np.diff(mind) <= 1e-9).all()
+    new_xyz = np.ascontiguousarray(xyz[:, sel])
+    for r, ns in [(0.2, 16), (0.8, 32)]:
+        idx_bo, idx_bd = bq_both(ext, oracle, new_xyz, xyz, r, ns, fill=0)
+        assert np.array_equal(idx_bo, idx_bd)
+        rows = idx_bd[0]
+        first = rows[:, :1]
+        # rows are ascending up to the padding, which repeats the first hit
+        body_ok = (np.diff(rows, axis=1) > 0) | (rows[:, 1:] == first)
+        assert body_ok.all()
+        dd = ((xyz[0][rows] - new_xyz[0][:, None]) ** 2).sum(-1)
+        assert (dd < r * r * (1 + 1e-5)).all()              # every listed neighbour is inside the ball
