@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 5
+#define PDA_POINTNET2_ABI_VERSION 6
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -125,6 +125,18 @@ int pda_three_interpolate(const float *points, const int32_t *idx, const float *
 int pda_three_interpolate_grad(const float *grad_out, const int32_t *idx, const float *weight,
                                float *grad_points, int b, int c, int n, int m,
                                pda_stream_t stream);
+
+/* ---- Chamfer 1-NN distance ------------------------------------ */
+/* replaces chamfer_forward (chamfer_cuda.cpp:22-25 -> chamferthreed.cu:136-153; kernel :12-134).
+ * xyz1 (b,n,3), xyz2 (b,m,3) -> dist1 (b,n) squared distance to / idx1 (b,n) index of the nearest
+ * point of xyz2 (lowest index on ties), and dist2/idx2 (b,m) the other way round. */
+int pda_chamfer_forward(const float *xyz1, const float *xyz2, float *dist1, float *dist2,
+                        int32_t *idx1, int32_t *idx2, int b, int n, int m, pda_stream_t stream);
+/* replaces chamfer_backward (chamfer_cuda.cpp:27-31 -> chamferthreed.cu:176-195; kernel :155-174).
+ * gradxyz1 (b,n,3) / gradxyz2 (b,m,3) pre-zeroed, accumulated into. */
+int pda_chamfer_backward(const float *xyz1, const float *xyz2, float *gradxyz1, float *gradxyz2,
+                         const float *graddist1, const float *graddist2, const int32_t *idx1,
+                         const int32_t *idx2, int b, int n, int m, pda_stream_t stream);
 
 /* ---- fused set-abstraction scale (MI355X extension) --------------------------------- */
 /* One scale of a vanilla SA layer in inference form, fused into one kernel:

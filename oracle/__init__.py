@@ -8,7 +8,7 @@ Parity status: "parity unpinned" at the CUDA boundary (see pointnet2_oracle.c he
 DESIGN.md): the reference ships no tests/golden vectors for this path and its CUDA sources
 cannot be built in this image.
 
-The functions mirror the 12 reference extension entry points on this path
+The functions mirror the reference extension entry points on this path
 (/root/reference/pcdet/ops/pointnet2/pointnet2_batch/src/pointnet2_api.cpp:12-33) with the
 same positional signatures, operating in place on C-contiguous numpy arrays
 (float32 / int32) instead of CUDA tensors.
@@ -30,4 +30,6 @@ from .binding import (  # noqa: F401
     three_nn_wrapper,
     three_interpolate_wrapper,
     three_interpolate_grad_wrapper,
+    chamfer_forward,
+    chamfer_backward,
 )

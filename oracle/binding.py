@@ -125,3 +125,20 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     _lib().pda_oracle_three_interpolate_grad(b, c, n, m, _f(grad_out, (b, c, n)),
                                              _i(idx, (b, n, 3)), _f(weight, (b, n, 3)),
                                              _f(grad_points, (b, c, m)))
+
+
+def chamfer_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    """chamfer_cuda.cpp:22-25; tensors only, sizes from the shapes as in the reference."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    return _lib().pda_oracle_chamfer_forward(b, n, m, _f(xyz1, (b, n, 3)), _f(xyz2, (b, m, 3)), _f(dist1, (b, n)),
+                                             _f(dist2, (b, m)), _i(idx1, (b, n)), _i(idx2, (b, m)))
+
+
+def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    return _lib().pda_oracle_chamfer_backward(b, n, m, _f(xyz1, (b, n, 3)), _f(xyz2, (b, m, 3)),
+                                              _f(gradxyz1, (b, n, 3)), _f(gradxyz2, (b, m, 3)),
+                                              _f(graddist1, (b, n)), _f(graddist2, (b, m)),
+                                              _i(idx1, (b, n)), _i(idx2, (b, m)))

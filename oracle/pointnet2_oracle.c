@@ -348,3 +348,78 @@ PDA_EXPORT void pda_oracle_three_interpolate_grad(int b, int c, int n, int m,
             }
         }
 }
+
+/* chamferthreed.cu:12-134 NmDistanceKernel, one direction: for every point j of `xyz` (b,n,3) the
+ * squared distance to, and index of, its nearest point of `xyz2` (b,m,3).  The reference scans
+ * xyz2 in shared-memory tiles of 512; inside a tile the first element initialises `best`
+ * (`k==0 || d<best`, :32/:117) and later ones replace it on strict '<'; across tiles the earlier
+ * tile is kept unless the later one is strictly smaller (`k2==0 || result > best`, :124).  Net:
+ * arg-min with the LOWEST index among equal distances.  d = x2*x2+y2*y2+z2*z2 on
+ * (target - query) differences (:30-33), contracted as nvcc would.  m == 0: outputs untouched. */
+static void nm_distance(int b, int n, const float *xyz, int m, const float *xyz2, float *result,
+                        int *result_i) {
+    const int batch = 512;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float x1 = xyz[((size_t)i * n + j) * 3 + 0];
+            const float y1 = xyz[((size_t)i * n + j) * 3 + 1];
+            const float z1 = xyz[((size_t)i * n + j) * 3 + 2];
+            for (int k2 = 0; k2 < m; k2 += batch) {
+                const int end_k = (m < k2 + batch ? m : k2 + batch) - k2;
+                const float *buf = xyz2 + ((size_t)i * m + k2) * 3;
+                int best_i = 0;
+                float best = 0;
+                for (int k = 0; k < end_k; ++k) {
+                    const float x2 = buf[k * 3 + 0] - x1, y2 = buf[k * 3 + 1] - y1, z2 = buf[k * 3 + 2] - z1;
+#if PDA_ORACLE_CONTRACT
+                    const float d = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+#else
+                    const float d = (x2 * x2 + y2 * y2) + z2 * z2;
+#endif
+                    if (k == 0 || d < best) { best = d; best_i = k + k2; }
+                }
+                if (k2 == 0 || result[(size_t)i * n + j] > best) {
+                    result[(size_t)i * n + j] = best;
+                    result_i[(size_t)i * n + j] = best_i;
+                }
+            }
+        }
+}
+
+/* chamferthreed.cu:136-153 chamfer_cuda_forward: both directions; returns 1 */
+PDA_EXPORT int pda_oracle_chamfer_forward(int b, int n, int m, const float *xyz1, const float *xyz2,
+                                          float *dist1, float *dist2, int *idx1, int *idx2) {
+    nm_distance(b, n, xyz1, m, xyz2, dist1, idx1);
+    nm_distance(b, m, xyz2, n, xyz1, dist2, idx2);
+    return 1;
+}
+
+/* chamferthreed.cu:155-174 NmDistanceGradKernel (atomicAdd; here sequential) */
+static void nm_distance_grad(int b, int n, const float *xyz1, int m, const float *xyz2,
+                             const float *grad_dist1, const int *idx1, float *grad_xyz1, float *grad_xyz2) {
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < n; ++j) {
+            const float x1 = xyz1[((size_t)i * n + j) * 3 + 0], y1 = xyz1[((size_t)i * n + j) * 3 + 1],
+                        z1 = xyz1[((size_t)i * n + j) * 3 + 2];
+            const int j2 = idx1[(size_t)i * n + j];
+            const float x2 = xyz2[((size_t)i * m + j2) * 3 + 0], y2 = xyz2[((size_t)i * m + j2) * 3 + 1],
+                        z2 = xyz2[((size_t)i * m + j2) * 3 + 2];
+            const float g = grad_dist1[(size_t)i * n + j] * 2;
+            grad_xyz1[((size_t)i * n + j) * 3 + 0] += g * (x1 - x2);
+            grad_xyz1[((size_t)i * n + j) * 3 + 1] += g * (y1 - y2);
+            grad_xyz1[((size_t)i * n + j) * 3 + 2] += g * (z1 - z2);
+            grad_xyz2[((size_t)i * m + j2) * 3 + 0] += -(g * (x1 - x2));
+            grad_xyz2[((size_t)i * m + j2) * 3 + 1] += -(g * (y1 - y2));
+            grad_xyz2[((size_t)i * m + j2) * 3 + 2] += -(g * (z1 - z2));
+        }
+}
+
+/* chamferthreed.cu:176-195 chamfer_cuda_backward: gradxyz1/2 pre-zeroed by the caller; returns 1 */
+PDA_EXPORT int pda_oracle_chamfer_backward(int b, int n, int m, const float *xyz1, const float *xyz2,
+                                           float *gradxyz1, float *gradxyz2, const float *graddist1,
+                                           const float *graddist2, const int *idx1, const int *idx2) {
+    nm_distance_grad(b, n, xyz1, m, xyz2, graddist1, idx1, gradxyz1, gradxyz2);
+    nm_distance_grad(b, m, xyz2, n, xyz1, graddist2, idx2, gradxyz2, gradxyz1);
+    return 1;
+}

@@ -7,8 +7,8 @@ pointnet2`` unchanged.  Each wrapper validates like the reference's CHECK_INPUT
 (ball_query.cpp:17-29: CUDA tensor + contiguous), launches the HIP kernel on torch's CURRENT
 stream through the C ABI (include/pda_pointnet2.h) and returns what the reference returns
 (1, 2 for the with-dist FPS, None for the interpolate trio).  Where the reference prints and
-calls exit(-1), this raises.  ``ellipsoid_query`` / ``chamfer_*`` are not on the PDA-SSD path
- and are not provided.
+calls exit(-1), this raises.  ``ellipsoid_query`` is not reached by PDA-SSD.yaml (SURVEY.md 2.1) and is not provided;
+``chamfer_forward/backward`` are.
 """
 import ctypes
 
@@ -162,3 +162,24 @@ def three_interpolate_grad_wrapper(b, c, n, m, grad_out, idx, weight, grad_point
     _call("pda_three_interpolate_grad", grad_out, _chk(grad_out, "grad_out", F32),
           _chk(idx, "idx", I32), _chk(weight, "weight", F32),
           _chk(grad_points, "grad_points", F32), b, c, n, m)
+
+
+def chamfer_forward(xyz1, xyz2, dist1, dist2, idx1, idx2):
+    """chamfer_cuda.cpp:22-25: tensors only, sizes come from the shapes.  Returns 1."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    _numel_ok(dist1, b * n, "dist1"); _numel_ok(dist2, b * m, "dist2")
+    _numel_ok(idx1, b * n, "idx1"); _numel_ok(idx2, b * m, "idx2")
+    _call("pda_chamfer_forward", xyz1, _chk(xyz1, "xyz1", F32), _chk(xyz2, "xyz2", F32), _chk(dist1, "dist1", F32),
+          _chk(dist2, "dist2", F32), _chk(idx1, "idx1", I32), _chk(idx2, "idx2", I32), b, n, m)
+    return 1
+
+
+def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1, idx2):
+    """chamfer_cuda.cpp:27-31.  gradxyz1/2 pre-zeroed by the caller.  Returns 1."""
+    b, n, _ = xyz1.shape
+    m = xyz2.shape[1]
+    _call("pda_chamfer_backward", xyz1, _chk(xyz1, "xyz1", F32), _chk(xyz2, "xyz2", F32),
+          _chk(gradxyz1, "gradxyz1", F32), _chk(gradxyz2, "gradxyz2", F32), _chk(graddist1, "graddist1", F32),
+          _chk(graddist2, "graddist2", F32), _chk(idx1, "idx1", I32), _chk(idx2, "idx2", I32), b, n, m)
+    return 1

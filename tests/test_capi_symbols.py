@@ -35,7 +35,7 @@ def test_binding_covers_header():
 
 
 def test_info_entry_points(lib, oracle):
-    assert lib.pda_abi_version() == 5
+    assert lib.pda_abi_version() == 6
     assert lib.pda_fp_contract_mode() == 1
     for n in [1, 2, 3, 7, 8, 100, 1000, 1023, 1024, 4096, 16384, 60000, 65536]:
         assert lib.pda_opt_n_threads(n) == oracle.opt_n_threads(n)
@@ -61,7 +61,8 @@ def test_mirror_module_matches_reference_names():
     for name in ["ball_query_wrapper", "ball_query_dilated_wrapper", "group_points_wrapper",
                  "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
                  "farthest_point_sampling_wrapper", "furthest_point_sampling_with_dist_wrapper",
-                 "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+                 "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper",
+                 "chamfer_forward", "chamfer_backward"]:
         assert callable(getattr(ext, name))
 
 

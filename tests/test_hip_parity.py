@@ -380,3 +380,42 @@ def test_config5_sizes_fps_and_ball_query(ext, oracle):
         assert body_ok.all()
         dd = ((xyz[0][rows] - new_xyz[0][:, None]) ** 2).sum(-1)
         assert (dd < r * r * (1 + 1e-5)).all()              # every listed neighbour is inside the ball
+
+
+# ---------------------------------------------------------------- Chamfer
+@pytest.mark.parametrize("b,n,m", [(2, 1024, 1024), (2, 4096, 300), (1, 7, 1500), (3, 1, 1), (1, 513, 512)])
+def test_chamfer_forward_backward(ext, oracle, b, n, m):
+    xyz1 = cloud(b, max(n, 8), seed=n)[:, :n].copy()
+    xyz2 = cloud(b, max(m, 8), seed=m + 3)[:, :m].copy()
+    d1 = np.zeros((b, n), np.float32); d2 = np.zeros((b, m), np.float32)
+    i1 = np.zeros((b, n), np.int32); i2 = np.zeros((b, m), np.int32)
+    oracle.chamfer_forward(xyz1, xyz2, d1, d2, i1, i2)
+    D1 = torch.zeros((b, n), device="cuda"); D2 = torch.zeros((b, m), device="cuda")
+    I1 = torch.zeros((b, n), dtype=torch.int32, device="cuda"); I2 = torch.zeros((b, m), dtype=torch.int32, device="cuda")
+    assert ext.chamfer_forward(dev(xyz1), dev(xyz2), D1, D2, I1, I2) == 1
+    assert np.array_equal(i1, I1.cpu().numpy()) and np.array_equal(i2, I2.cpu().numpy())
+    assert np.array_equal(d1, D1.cpu().numpy()) and np.array_equal(d2, D2.cpu().numpy())
+    rng = np.random.default_rng(0)
+    gd1 = rng.normal(size=(b, n)).astype(np.float32); gd2 = rng.normal(size=(b, m)).astype(np.float32)
+    g1 = np.zeros_like(xyz1); g2 = np.zeros_like(xyz2)
+    oracle.chamfer_backward(xyz1, xyz2, g1, g2, gd1, gd2, i1, i2)
+    G1 = torch.zeros((b, n, 3), device="cuda"); G2 = torch.zeros((b, m, 3), device="cuda")
+    assert ext.chamfer_backward(dev(xyz1), dev(xyz2), G1, G2, dev(gd1), dev(gd2), I1, I2) == 1
+    np.testing.assert_allclose(G1.cpu().numpy(), g1, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(G2.cpu().numpy(), g2, rtol=1e-4, atol=1e-3)
+
+
+def test_chamfer_ties_and_loss_module(ext, oracle):
+    rng = np.random.default_rng(9)
+    xyz1 = rng.integers(0, 4, size=(2, 700, 3)).astype(np.float32)   # lattice: many equidistant targets
+    xyz2 = rng.integers(0, 4, size=(2, 1300, 3)).astype(np.float32)
+    d1 = np.zeros((2, 700), np.float32); d2 = np.zeros((2, 1300), np.float32)
+    i1 = np.zeros((2, 700), np.int32); i2 = np.zeros((2, 1300), np.int32)
+    oracle.chamfer_forward(xyz1, xyz2, d1, d2, i1, i2)
+    from pdanet_amd import chamfer_distance as cdm
+    a = dev(xyz1).requires_grad_(True)
+    D1, D2, I1, I2 = cdm.chamfer_3DFunction.apply(a, dev(xyz2))
+    assert np.array_equal(i1, I1.cpu().numpy()) and np.array_equal(i2, I2.cpu().numpy())
+    loss = cdm.cd_loss_L2(a, dev(xyz2))
+    loss.backward()
+    assert abs(float(loss.detach()) - (d1.mean() + d2.mean())) < 1e-4 and torch.isfinite(a.grad).all()

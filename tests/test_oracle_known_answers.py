@@ -234,3 +234,23 @@ def test_three_interpolate_and_grad(oracle):
     oracle.three_interpolate_grad_wrapper(b, c, n, m, go, idx, w, gp)
     assert gp[0, 0].tolist() == [0.5 + 0.5, 0.25, 0.25, 1.0 + 0.5]
     assert gp[0, 1].tolist() == [2 + 2, 1, 1, 4 + 2]
+
+
+def test_chamfer_semantics(oracle):
+    # chamferthreed.cu:12-134: nearest point, LOWEST index among equal distances, also across the
+    # 512-point tiles (:124 keeps the earlier tile unless strictly smaller)
+    xyz1 = np.zeros((1, 2, 3), np.float32); xyz1[0, 1, 0] = 10
+    xyz2 = np.zeros((1, 1100, 3), np.float32); xyz2[0, :, 0] = 5
+    xyz2[0, 3, 0] = 1; xyz2[0, 700, 0] = 1; xyz2[0, 1050, 0] = -1   # three equidistant (d2 = 1) from the origin
+    xyz2[0, 600, 0] = 9.5
+    d1 = np.zeros((1, 2), np.float32); d2 = np.zeros((1, 1100), np.float32)
+    i1 = np.zeros((1, 2), np.int32); i2 = np.zeros((1, 1100), np.int32)
+    assert oracle.chamfer_forward(xyz1, xyz2, d1, d2, i1, i2) == 1
+    assert i1[0].tolist() == [3, 600] and d1[0].tolist() == [1.0, 0.25]
+    assert i2[0, 3] == 0 and i2[0, 600] == 1 and d2[0, 0] == 25.0
+    # gradient: d(dist1_j)/d(p1_j) = 2 (p1_j - p2_idx), and the opposite sign on the target
+    g1 = np.zeros_like(xyz1); g2 = np.zeros_like(xyz2)
+    gd1 = np.ones((1, 2), np.float32); gd2 = np.zeros((1, 1100), np.float32)
+    assert oracle.chamfer_backward(xyz1, xyz2, g1, g2, gd1, gd2, i1, i2) == 1
+    assert g1[0, 0].tolist() == [-2.0, 0.0, 0.0] and g1[0, 1].tolist() == [1.0, 0.0, 0.0]
+    assert g2[0, 3].tolist() == [2.0, 0.0, 0.0] and g2[0, 600].tolist() == [-1.0, 0.0, 0.0]
