@@ -419,3 +419,36 @@ def test_chamfer_ties_and_loss_module(ext, oracle):
     loss = cdm.cd_loss_L2(a, dev(xyz2))
     loss.backward()
     assert abs(float(loss.detach()) - (d1.mean() + d2.mean())) < 1e-4 and torch.isfinite(a.grad).all()
+
+
+# ---------------------------------------------------------------- randomized shapes
+def test_random_shapes_indices_exact(ext, oracle):
+    """Seeded sweep over odd shapes: N not a power of two (block-size selection / tie-break width),
+    N < 1024, M not a multiple of 64, ns in {1..64}, clustered + lattice + uniform clouds."""
+    rng = np.random.default_rng(20260101)
+    for case in range(40):
+        b = int(rng.integers(1, 4))
+        n = int(rng.choice([1, 2, 3, 5, 17, 63, 64, 65, 127, 500, 1023, 1024, 1025, 2047, 2048, 2049, 3000, 5000, 9999]))
+        kind = case % 3
+        if kind == 0:
+            xyz = rng.uniform(-20, 20, size=(b, n, 3)).astype(np.float32)
+        elif kind == 1:
+            xyz = rng.integers(0, 5, size=(b, n, 3)).astype(np.float32)          # exact ties everywhere
+        else:
+            xyz = (rng.normal(size=(b, n, 3)) * np.array([8, 8, 0.3])).astype(np.float32)
+        m = int(rng.integers(1, n + 1))
+        idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+        assert np.array_equal(idx_o, idx_d), ("fps", case, b, n, m)
+        assert np.array_equal(temp_o, temp_d), ("fps temp", case, b, n, m)
+        mc = int(rng.integers(1, 200))
+        new_xyz = (xyz[:, rng.integers(0, n, mc)] + rng.normal(scale=0.2, size=(b, mc, 3))).astype(np.float32)
+        new_xyz = np.ascontiguousarray(new_xyz)
+        ns = int(rng.choice([1, 2, 3, 7, 16, 32, 33, 64]))
+        r = float(rng.choice([0.5, 1.0, 2.5, 6.0]))
+        io, idd = bq_both(ext, oracle, new_xyz, xyz, r, ns, fill=-4)
+        assert np.array_equal(io, idd), ("ball_query", case, b, n, mc, r, ns)
+        d_o = np.zeros((b, mc, 3), np.float32); i_o = np.zeros((b, mc, 3), np.int32)
+        oracle.three_nn_wrapper(b, mc, n, new_xyz, xyz, d_o, i_o)
+        d_d = torch.zeros((b, mc, 3), device="cuda"); i_d = torch.zeros((b, mc, 3), dtype=torch.int32, device="cuda")
+        ext.three_nn_wrapper(b, mc, n, dev(new_xyz), dev(xyz), d_d, i_d)
+        assert np.array_equal(i_o, i_d.cpu().numpy()) and np.array_equal(d_o, d_d.cpu().numpy()), ("three_nn", case)
