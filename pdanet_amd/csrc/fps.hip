@@ -21,12 +21,17 @@
 //   points per v_pk_{add,mul,fma}_f32 is 13 % SLOWER (5.40 vs 4.79 ms: packed f32 issues at half
 //   rate and costs extra moves), 512 lanes x 32 points/lane 22-36 % slower (fewer waves to
 //   cover the reduction latency).
-// fps_stream_kernel<WITH_DIST> (any N; also the (B,N,N) distance-matrix variant)
+// fps_pruned_kernel<P,COOP> (2048 <= N <= 16384 single workgroup; 24576 < N <= 65536 cooperative:
+//   K = ceil(N/16384) workgroups per scene, see the comment at the kernel)
+// fps_stream_kernel<WITH_DIST> (any other N; also the (B,N,N) distance-matrix variant)
 //   * same reduction, but xyz (or the dist row) and temp stream from L2/HBM each iteration.
 // Algorithmic bytes: (m-1)*N*20 + m*4 per scene; compulsory bytes N*16 + m*4.
 #include "pda_common.h"
 
 #include <stdlib.h>
+
+#include <algorithm>
+#include <atomic>
 
 namespace pda {
 
@@ -156,23 +161,42 @@ __device__ __forceinline__ void fps_extract(int js, int lstar, const float (&px)
 __device__ unsigned long long g_fps_stats[4];  // [0] wave-scans, [1] wave-rounds, [2] hit lanes
 #endif
 
-template <int P>
+// Cooperative form (COOP): K workgroups share one scene (16384 < N <= 65536).  Workgroup g owns the
+// contiguous index range [g*ceil(N/K), ...) -- an arbitrary quarter of the shuffled cloud, sorted and
+// pruned locally exactly as above -- and every round the K local winners are exchanged through
+// 8-byte {payload, tag} granules in device memory (relaxed agent-scope 64-bit atomics = sc1
+// stores/loads, MI355X_MICROARCH.md "Valid forms": a granule needs no further ordering; the tag is
+// (launch epoch, round)).  Each workgroup then reduces the K records with the same total order, so
+// all of them continue with the same sample.  Requires the K workgroups of a scene to be resident
+// together (host: grid <= 256 workgroups); every poll loop is bounded (FPS_SPIN_LIMIT).
+constexpr int FPS_XBUF_REGIONS = 4, FPS_XBUF_SCENES = 64, FPS_MAX_K = 4, FPS_SPIN_LIMIT = 1 << 20;
+__device__ unsigned long long g_fps_xbuf[FPS_XBUF_REGIONS * FPS_XBUF_SCENES * 2 * FPS_MAX_K * 5];
+
+template <int P, bool COOP>
 __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __restrict__ xyz_all,
                                                                   float* __restrict__ temp_all,
-                                                                  int32_t* __restrict__ idx_all, int n,
-                                                                  int m, int L) {
+                                                                  int32_t* __restrict__ idx_all, int n_total,
+                                                                  int m, int L, int K, int nb, uint32_t epoch) {
     constexpr int NS = FPS_THREADS * P;  // sort size (power of two)
     __shared__ uint32_t skey[NS];
     __shared__ float red[FPS_WAVES * 6];
     __shared__ uint2 slots[2][FPS_WAVES];
     __shared__ float4 cand[2][FPS_WAVES];
+    __shared__ int failflag;
     const int t = threadIdx.x;
     const int lane = lane_id();
     const int w = wave_id();
-    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
-    float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
-    int32_t* __restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+    const int scene = COOP ? (int)(blockIdx.x % nb) : (int)blockIdx.x;
+    const int g = COOP ? (int)(blockIdx.x / nb) : 0;      // my share of the scene
+    const int nper = COOP ? (n_total + K - 1) / K : n_total;
+    const int k_lo = g * nper;                             // first global index I own
+    const int n = max(0, min(n_total, k_lo + nper) - k_lo);  // points I own (local indices 0..n-1)
+    const float* __restrict__ xyz0 = xyz_all + (size_t)scene * n_total * 3;  // the scene
+    const float* __restrict__ xyz = xyz0 + (size_t)k_lo * 3;                 // my range
+    float* __restrict__ temp = temp_all + (size_t)scene * n_total + k_lo;
+    int32_t* __restrict__ idx = idx_all + (size_t)scene * m;
     const float INF = __builtin_inff();
+    if (t == 0) failflag = 0;
 
     // ---- 1. scene bounding box ---------------------------------------------------------
     float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
@@ -264,7 +288,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
         const uint32_t e = skey[t * P + i];
         const bool valid = e != 0xffffffffu;
         kk[i] = valid ? (int)(e & 0x3fffu) : -1;
-        kT[i] = valid ? fps_tiebreak((uint32_t)kk[i], L) : 0xffffffffu;
+        kT[i] = valid ? fps_tiebreak((uint32_t)(kk[i] + k_lo), L) : 0xffffffffu;  // global index
     }
 #pragma unroll
     for (int k2 = 2; k2 <= P; k2 <<= 1)
@@ -310,8 +334,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
     bool publish = false;
 
     int old = 0;
-    if (t == 0) idx[0] = 0;
-    float x1 = xyz[0], y1 = xyz[1], z1 = xyz[2];
+    if (t == 0 && g == 0) idx[0] = 0;
+    float x1 = xyz0[0], y1 = xyz0[1], z1 = xyz0[2];   // point 0 of the SCENE
     for (int j = 1; j < m; ++j) {
         // ---- conservative box test of my cluster against the new sample ----------------
         const float ex = fmaxf(fmaxf(blo[0] - x1, x1 - bhi[0]), 0.f);
@@ -388,18 +412,63 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
             const float v = __builtin_bit_cast(float, sv.x);
             const float bmax = row0_max_f32(v);
             const uint32_t bTw = row0_min_u32(v == bmax ? sv.y : 0xffffffffu);
-            // exactly one slot holds (bmax, bT): that lane forwards its record
-            if (lane < FPS_WAVES && v == bmax && sv.y == bTw)
-                cand[1][0] = make_float4(c4.x, c4.y, c4.z, __builtin_bit_cast(float, bTw));
+            if (!COOP) {
+                // exactly one slot holds (bmax, bT): that lane forwards its record
+                if (lane < FPS_WAVES && v == bmax && sv.y == bTw)
+                    cand[1][0] = make_float4(c4.x, c4.y, c4.z, __builtin_bit_cast(float, bTw));
+            } else {
+                const unsigned long long wm = __ballot(lane < FPS_WAVES && v == bmax && sv.y == bTw);
+                const int lw = __builtin_amdgcn_readfirstlane((int)__builtin_ctzll(wm | (1ull << 63)) & (FPS_WAVES - 1));
+                const uint32_t r0 = __builtin_bit_cast(uint32_t, bmax), r1 = bTw;
+                const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, c4.x), lw);
+                const uint32_t r3 = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, c4.y), lw);
+                const uint32_t r4 = (uint32_t)__builtin_amdgcn_readlane(__builtin_bit_cast(int, c4.z), lw);
+                // publish my record: 5 granules {payload, tag}
+                const uint32_t tag = (epoch << 17) | (uint32_t)j;  // 15-bit launch epoch | 17-bit round
+                unsigned long long* base = g_fps_xbuf +
+                    ((((size_t)(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + scene) * 2 + (j & 1)) * FPS_MAX_K) * 5;
+                if (lane < 5) {
+                    const uint32_t pay = lane == 0 ? r0 : (lane == 1 ? r1 : (lane == 2 ? r2 : (lane == 3 ? r3 : r4)));
+                    __hip_atomic_store(base + g * 5 + lane, ((unsigned long long)tag << 32) | pay, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+                }
+                // collect the K records (lane 5q+f polls field f of workgroup q), bounded spin
+                unsigned long long gv = 0;
+                bool ok = lane >= 5 * K;
+                bool failed = false;
+                for (int spin = 0;; ++spin) {
+                    if (!ok) {
+                        gv = __hip_atomic_load(base + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (uint32_t)(gv >> 32) == tag;
+                    }
+                    if (__ballot(!ok) == 0ull) break;
+                    if (spin > FPS_SPIN_LIMIT) { failed = true; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                const int pay = (int)(uint32_t)gv;
+                const int src = (5 * lane) & 63;
+                const uint32_t f0 = (uint32_t)__shfl(pay, src), f1 = (uint32_t)__shfl(pay, (src + 1) & 63);
+                const uint32_t f2 = (uint32_t)__shfl(pay, (src + 2) & 63), f3 = (uint32_t)__shfl(pay, (src + 3) & 63);
+                const uint32_t f4 = (uint32_t)__shfl(pay, (src + 4) & 63);
+                const float vq = lane < K ? __builtin_bit_cast(float, f0) : -1.0f;
+                const uint32_t tq = lane < K ? f1 : 0xffffffffu;
+                const float gmax = row0_max_f32(vq);
+                const uint32_t gT = row0_min_u32(vq == gmax ? tq : 0xffffffffu);
+                if (failed) { if (lane == 0) failflag = 1; }
+                if (lane < K && vq == gmax && tq == gT)
+                    cand[1][0] = make_float4(__builtin_bit_cast(float, f2), __builtin_bit_cast(float, f3),
+                                             __builtin_bit_cast(float, f4), __builtin_bit_cast(float, gT));
+            }
         }
         lds_barrier();
+        if (COOP && failflag) break;  // an exchange timed out: give up (bounded), outputs are invalid
         const float4 win = cand[1][0];
         x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.x)));
         y1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.y)));
         z1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.z)));
         const uint32_t bT = (uint32_t)__builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.w));
         old = (int)fps_tiebreak_decode(bT, L);
-        if (t == 0) idx[j] = old;
+        if (t == 0 && g == 0) idx[j] = old;
     }
 #pragma unroll
     for (int i = 0; i < P; ++i)
@@ -467,10 +536,25 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
     const int P = divup(n, FPS_THREADS);
     static const int no_prune = getenv("PDA_FPS_NO_PRUNE") ? atoi(getenv("PDA_FPS_NO_PRUNE")) : 0;
     if (!no_prune && n >= 2048 && n <= 16384 && m > 2) {
-        if (P <= 2) hipLaunchKernelGGL(fps_pruned_kernel<2>, grid, block, 0, stream, data, temp, idx, n, m, L);
-        else if (P <= 4) hipLaunchKernelGGL(fps_pruned_kernel<4>, grid, block, 0, stream, data, temp, idx, n, m, L);
-        else if (P <= 8) hipLaunchKernelGGL(fps_pruned_kernel<8>, grid, block, 0, stream, data, temp, idx, n, m, L);
-        else hipLaunchKernelGGL(fps_pruned_kernel<16>, grid, block, 0, stream, data, temp, idx, n, m, L);
+        if (P <= 2) hipLaunchKernelGGL((fps_pruned_kernel<2, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
+        else if (P <= 4) hipLaunchKernelGGL((fps_pruned_kernel<4, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
+        else if (P <= 8) hipLaunchKernelGGL((fps_pruned_kernel<8, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
+        else hipLaunchKernelGGL((fps_pruned_kernel<16, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
+        return check_launch(what);
+    }
+    static const int no_coop = getenv("PDA_FPS_NO_COOP") ? atoi(getenv("PDA_FPS_NO_COOP")) : 0;
+    // (16384, 24576] stays on the single-workgroup register kernel: 6.3 ms vs 7.7-9.0 ms cooperative
+    if (!no_prune && !no_coop && n > 24 * FPS_THREADS && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
+        // K workgroups per scene, all resident together: at most 256/K (and 64) scenes per launch
+        static std::atomic<uint32_t> epoch_counter{1};
+        const int K = divup(n, 16384);
+        const int chunk = std::min(FPS_XBUF_SCENES, 256 / K);
+        for (int s0 = 0; s0 < b; s0 += chunk) {
+            const int nb = std::min(chunk, b - s0);
+            const uint32_t epoch = epoch_counter.fetch_add(1) & 0x7fffu;
+            hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
+                               data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
+        }
         return check_launch(what);
     }
 #define PDA_FPS_CASE(PP)                                                                          \
