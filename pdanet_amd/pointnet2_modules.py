@@ -550,6 +550,10 @@ class Vote_layer(nn.Module):
             self.mlp_modules = None
         self.ctr_reg = nn.Conv1d(pre_channel, 3, kernel_size=1)
         self.max_offset_limit = torch.tensor(max_translate_range).float() if max_translate_range is not None else None
+        # device-resident copy (not in the state dict): the reference does a host->device copy of
+        # this 3-vector every forward (:1730), which also breaks hipGraph capture
+        self.register_buffer("_offset_limit", self.max_offset_limit.clone().view(1, 1, 3)
+                             if self.max_offset_limit is not None else None, persistent=False)
 
     def forward(self, xyz, features):
         xyz_select = xyz
@@ -558,7 +562,7 @@ class Vote_layer(nn.Module):
         new_features = ctr_offsets[..., 3:]
         ctr_offsets = ctr_offsets[..., :3]
         if self.max_offset_limit is not None:
-            lim = self.max_offset_limit.to(xyz_select.device).view(1, 1, 3)
+            lim = self._offset_limit
             limited = torch.where(ctr_offsets > lim, lim, ctr_offsets)
             limited = torch.where(limited < -lim, -lim, limited)
             vote_xyz = xyz_select + limited

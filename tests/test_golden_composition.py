@@ -228,3 +228,27 @@ def test_kitti_backbone_forward_backward_runs():
     n_grad = sum(1 for p in model.parameters() if p.grad is not None)
     assert n_grad >= 0.9 * sum(1 for _ in model.parameters())
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
+
+
+@gpu
+def test_inference_forward_captures_into_hipgraph():
+    """The whole backbone inference forward (side-stream D-FPS prefetch, fused SA kernels, point-
+    major PDA layers) is capturable: no allocation/synchronisation/host copies in the C ABI or the
+    model code.  Replay must reproduce the eager result bit for bit."""
+    from pdanet_amd import synth, fused_ops
+    from pdanet_amd.backbone import build_backbone
+    model, _ = build_backbone("once_pda_ssd.yaml")
+    model = fill_deterministic(model).cuda().eval()
+    fused_ops.enable_fused(model)
+    pts = torch.from_numpy(synth.batch_points(2, 4096, config_id=8)).cuda()
+    with torch.no_grad():
+        for _ in range(2):
+            ref = model({"batch_size": 2, "points": pts})["centers_features"].clone()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.no_grad(), torch.cuda.graph(g):
+        out = model({"batch_size": 2, "points": pts})["centers_features"]
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
