@@ -209,7 +209,8 @@ def main():
 
     scenes = args.batch * world * args.steps
     line = {
-        "metric": "scenes/sec (16384-pt ONCE, PDA-SSD hot path)",
+        "metric": "scenes/sec (%d-pt ONCE, PDA-SSD %s)" % (
+            args.points, "forward+backward" if "fwd_bwd" in wl.name else ("forward" if "fwd_eval" in wl.name else "sampling/grouping ops")),
         "value": scenes / dt,
         "unit": "scenes/s",
         "n_gpus": world,
