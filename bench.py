@@ -226,6 +226,8 @@ def main():
                    "parallelism": "dp%d" % world},
         "roofline": roof,
     }
+    if hasattr(wl, "tuned"):
+        line["config"]["hipblaslt_tunableop_results_loaded"] = bool(wl.tuned)
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = wl.cpu_baseline()
