@@ -14,21 +14,29 @@ namespace pda {
 
 constexpr int NN_BATCH = 8;
 
-__global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__ unknown,
+// 64 unknown points per workgroup (one per lane); the S waves of the workgroup scan S contiguous
+// segments of the known points and the S partial top-3 lists are merged in LDS by the
+// lexicographic key (d2, index) -- exactly the set and order the reference's sequential strict-'<'
+// scan produces -- so a small query (n/64 tiles x B) still fills the chip.
+__global__ __launch_bounds__(512) void three_nn_kernel(const float* __restrict__ unknown,
                                                         const float* __restrict__ known,
                                                         float* __restrict__ dist2,
-                                                        int32_t* __restrict__ idx, int n, int m) {
+                                                        int32_t* __restrict__ idx, int n, int m, int seglen) {
+    __shared__ float sd[8][3][64];
+    __shared__ int si[8][3][64];
     const int bs = blockIdx.y;
-    const int pt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int w = wave_id(), lane = lane_id(), S = (int)(blockDim.x >> 6);
+    const int pt = blockIdx.x * 64 + lane;
     const bool valid = pt < n;
     const float* uu = unknown + ((size_t)bs * n + min(pt, n - 1)) * 3;
     const float ux = uu[0], uy = uu[1], uz = uu[2];
     const cfloat_ptr kn = as_constant(uniform_ptr(known + (size_t)bs * m * 3));
     float b1 = __builtin_inff(), b2 = __builtin_inff(), b3 = __builtin_inff();
     int i1 = 0, i2 = 0, i3 = 0;
-    for (int k0 = 0; k0 < m; k0 += NN_BATCH) {
+    const int k_begin = w * seglen, k_end = min(m, k_begin + seglen);
+    for (int k0 = k_begin; k0 < k_end; k0 += NN_BATCH) {
         float px[NN_BATCH], py[NN_BATCH], pz[NN_BATCH];
-        const bool full = k0 + NN_BATCH <= m;
+        const bool full = k0 + NN_BATCH <= k_end;
 #pragma unroll
         for (int u = 0; u < NN_BATCH; ++u) {
             const int k = full ? k0 + u : min(k0 + u, m - 1);
@@ -38,13 +46,33 @@ __global__ __launch_bounds__(256) void three_nn_kernel(const float* __restrict__
         for (int u = 0; u < NN_BATCH; ++u) {
             const int k = k0 + u;
             float d = sqdist3(ux, uy, uz, px[u], py[u], pz[u]);  // (u - x), interpolate_gpu.cu:43
-            if (!full && k >= m) d = __builtin_inff();            // clamped duplicate: never '<'
+            if (!full && k >= k_end) d = __builtin_inff();        // outside my segment: never '<'
             // branch-free form of the if / else-if / else-if chain (:44-56)
             const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
             b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? k : i3);
             b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? k : i2);
             b1 = c1 ? d : b1;              i1 = c1 ? k : i1;
         }
+    }
+    if (S > 1) {
+        sd[w][0][lane] = b1; sd[w][1][lane] = b2; sd[w][2][lane] = b3;
+        si[w][0][lane] = i1; si[w][1][lane] = i2; si[w][2][lane] = i3;
+        __syncthreads();
+        if (w != 0) return;
+        // merge: candidates arrive in ascending index order (segment by segment, each list sorted
+        // by (d, index)); a candidate replaces on strict '<' only, so equal distances keep the lower
+        // index first, as in the sequential scan.  Untouched (inf, 0) entries never insert.
+        b1 = b2 = b3 = __builtin_inff(); i1 = i2 = i3 = 0;
+        for (int s = 0; s < S; ++s)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const float d = sd[s][q][lane];
+                const int k = si[s][q][lane];
+                const bool c1 = d < b1, c2 = d < b2, c3 = d < b3;
+                b3 = c2 ? b2 : (c3 ? d : b3);  i3 = c2 ? i2 : (c3 ? k : i3);
+                b2 = c1 ? b1 : (c2 ? d : b2);  i2 = c1 ? i1 : (c2 ? k : i2);
+                b1 = c1 ? d : b1;              i1 = c1 ? k : i1;
+            }
     }
     if (valid) {
         float* d = dist2 + ((size_t)bs * n + pt) * 3;
@@ -107,9 +135,13 @@ PDA_API int pda_three_nn(const float* unknown, const float* known, float* dist2,
     if (b == 0 || n == 0) return PDA_OK;
     PDA_REQUIRE(unknown && dist2 && idx && (known || m == 0), "pda_three_nn: null pointer");
     PDA_REQUIRE((int64_t)m * 3 < INT32_MAX && b <= 65535, "pda_three_nn: too large");
-    dim3 grid(pda::divup(n, 256), b), block(256);
+    const int tiles = pda::divup(n, 64);
+    int S = 1;
+    while (S < 8 && (int64_t)tiles * b * S < 4096 && pda::divup(m, S * 2) >= 256) S *= 2;
+    const int seglen = pda::divup(pda::divup(m, S), pda::NN_BATCH) * pda::NN_BATCH;
+    dim3 grid(tiles, b), block(64 * S);
     hipLaunchKernelGGL(pda::three_nn_kernel, grid, block, 0, (hipStream_t)stream, unknown, known, dist2,
-                       idx, n, m);
+                       idx, n, m, seglen);
     return pda::check_launch("pda_three_nn");
 }
 

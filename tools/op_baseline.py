@@ -104,6 +104,30 @@ def group_case(b, c, n, m, ns, tag):
         b * (m * ns * 4 + c * m * ns * 8), t1, tall, tg)
 
 
+def three_nn_case(b, n, m, c, tag):
+    unknown = synth.batch_xyz(b, n, config_id=2)
+    known = np.ascontiguousarray(unknown[:, :m])
+    d_o = np.zeros((b, n, 3), np.float32); i_o = np.zeros((b, n, 3), np.int32)
+    ud, kd = torch.from_numpy(unknown).cuda(), torch.from_numpy(known).cuda()
+    d_d = torch.zeros((b, n, 3), device="cuda"); i_d = torch.zeros((b, n, 3), dtype=torch.int32, device="cuda")
+    t1 = cpu_time(lambda: oracle.three_nn_wrapper(b, n, m, unknown, known, d_o, i_o), 1, 3)
+    tall = cpu_time(lambda: oracle.three_nn_wrapper(b, n, m, unknown, known, d_o, i_o), NCORES, 5)
+    tg = gpu_time(lambda: ext.three_nn_wrapper(b, n, m, ud, kd, d_d, i_d))
+    assert np.array_equal(i_o, i_d.cpu().numpy()) and np.array_equal(d_o, d_d.cpu().numpy()), "parity gate failed: three_nn"
+    row("three_nn n=%d m=%d, %d scenes (%s)" % (n, m, b, tag), b * (-(-n // 256) * m * 12 + n * 36), t1, tall, tg)
+    rng = np.random.default_rng(1)
+    pts = rng.normal(size=(b, c, m)).astype(np.float32)
+    w = rng.uniform(0.1, 1, size=(b, n, 3)).astype(np.float32); w /= w.sum(-1, keepdims=True)
+    out_o = np.zeros((b, c, n), np.float32)
+    pd, wd = torch.from_numpy(pts).cuda(), torch.from_numpy(w).cuda()
+    out_d = torch.empty((b, c, n), device="cuda")
+    t1 = cpu_time(lambda: oracle.three_interpolate_wrapper(b, c, m, n, pts, i_o, w, out_o), 1, 3)
+    tall = cpu_time(lambda: oracle.three_interpolate_wrapper(b, c, m, n, pts, i_o, w, out_o), NCORES, 5)
+    tg = gpu_time(lambda: ext.three_interpolate_wrapper(b, c, m, n, pd, i_d, wd, out_d))
+    assert np.abs(out_o - out_d.cpu().numpy()).max() <= 1e-4, "parity gate failed: three_interpolate (1e-4)"
+    row("three_interpolate C=%d n=%d, %d scenes (%s)" % (c, n, b, tag), b * (n * 24 + c * n * 16), t1, tall, tg)
+
+
 def main():
     print("## Operator baseline: CPU oracle vs HIP kernels on the same box\n")
     print("Host: %d hardware threads (`nproc`), CPU oracle = oracle/libpda_oracle.so (gcc -O3 -mavx2 -mfma, OpenMP); "
@@ -123,6 +147,7 @@ def main():
     bq_case(2, 16384, 4096, 1.6, 32, "config 2, layer 1")
     group_case(2, 4, 16384, 16384, 32, "config 2, layer 0")
     group_case(2, 67, 16384, 4096, 32, "config 2, layer 1")
+    three_nn_case(2, 16384, 4096, 128, "SURVEY 8a row a5 shape")
 
 
 if __name__ == "__main__":
