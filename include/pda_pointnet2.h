@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 6
+#define PDA_POINTNET2_ABI_VERSION 7
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -137,6 +137,21 @@ int pda_chamfer_forward(const float *xyz1, const float *xyz2, float *dist1, floa
 int pda_chamfer_backward(const float *xyz1, const float *xyz2, float *gradxyz1, float *gradxyz2,
                          const float *graddist1, const float *graddist2, const int32_t *idx1,
                          const int32_t *idx2, int b, int n, int m, pda_stream_t stream);
+
+/* ---- per-group self-attention (MI355X extension) ------------------------------------ */
+/* The attention of the PDA layer's TransformerEncoderLayerPreNorm (PointFormer.py:30-33,
+ * nn.MultiheadAttention without mask/dropout) over sequences of `seq` = nsample tokens:
+ *   qkv (num_groups, seq, 3, heads, head_dim) = the in_proj output; out (num_groups, seq,
+ *   heads*head_dim) = softmax(Q K^T / sqrt(head_dim)) V, ready for out_proj;
+ *   lse (num_groups, heads, seq) = log-sum-exp per query, kept for the backward pass.
+ * seq in {8,16,32}, head_dim in {32,64,128}; anything else returns PDA_ERR_UNSUPPORTED (callers
+ * then use the framework's scaled_dot_product_attention).  fp32 MFMA, fp32 accumulate. */
+int pda_group_attention_fwd(const float *qkv, float *out, float *lse, int64_t num_groups, int seq,
+                            int heads, int head_dim, pda_stream_t stream);
+/* grad_qkv (num_groups, seq, 3, heads, head_dim) is fully written (no pre-zeroing needed). */
+int pda_group_attention_bwd(const float *qkv, const float *grad_out, const float *lse,
+                            float *grad_qkv, int64_t num_groups, int seq, int heads, int head_dim,
+                            pda_stream_t stream);
 
 /* ---- fused set-abstraction scale (MI355X extension) --------------------------------- */
 /* One scale of a vanilla SA layer in inference form, fused into one kernel:

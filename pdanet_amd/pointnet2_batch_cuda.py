@@ -183,3 +183,20 @@ def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1,
           _chk(gradxyz1, "gradxyz1", F32), _chk(gradxyz2, "gradxyz2", F32), _chk(graddist1, "graddist1", F32),
           _chk(graddist2, "graddist2", F32), _chk(idx1, "idx1", I32), _chk(idx2, "idx2", I32), b, n, m)
     return 1
+
+
+def group_attention_fwd(qkv, out, lse, num_groups, seq, heads, head_dim):
+    """MI355X extension: attention over the tokens of each group (csrc/group_attention.hip)."""
+    _numel_ok(qkv, num_groups * seq * 3 * heads * head_dim, "qkv")
+    _numel_ok(out, num_groups * seq * heads * head_dim, "out"); _numel_ok(lse, num_groups * heads * seq, "lse")
+    _call("pda_group_attention_fwd", qkv, _chk(qkv, "qkv", F32), _chk(out, "out", F32), _chk(lse, "lse", F32),
+          num_groups, seq, heads, head_dim)
+    return 1
+
+
+def group_attention_bwd(qkv, grad_out, lse, grad_qkv, num_groups, seq, heads, head_dim):
+    _numel_ok(qkv, num_groups * seq * 3 * heads * head_dim, "qkv"); _numel_ok(grad_qkv, qkv.numel(), "grad_qkv")
+    _numel_ok(grad_out, num_groups * seq * heads * head_dim, "grad_out"); _numel_ok(lse, num_groups * heads * seq, "lse")
+    _call("pda_group_attention_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32),
+          _chk(lse, "lse", F32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
+    return 1

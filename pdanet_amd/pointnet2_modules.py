@@ -66,6 +66,7 @@ class TransformerEncoderLayerPreNorm(nn.Module):
 # transformer consumes the tensor batch-first without any relayout.  Same parameters, same
 # state-dict, same math; only summation orders differ.
 CHANNELS_LAST = True
+GROUP_ATTENTION_KERNEL = True   # csrc/group_attention.hip instead of scaled_dot_product_attention
 
 
 def _bn_lastdim(bn, x):
@@ -103,9 +104,11 @@ def _transformer_batch_first(tr, x):
     src = F.layer_norm(x, (D,), tr.norm1.weight, tr.norm1.bias, tr.norm1.eps)
     qkv = F.linear(src, attn.in_proj_weight, attn.in_proj_bias)
     Bn, S, _ = qkv.shape
-    q, k, v = qkv.view(Bn, S, 3, H, D // H).permute(2, 0, 3, 1, 4)  # each (Bn, H, S, hd)
-    a = F.scaled_dot_product_attention(q, k, v)
-    a = a.transpose(1, 2).reshape(Bn, S, D)
+    if GROUP_ATTENTION_KERNEL and pointnet2_utils.GroupAttention.supported(qkv, H):
+        a = pointnet2_utils.group_attention(qkv, H)              # one wave per (group, head), fp32 MFMA
+    else:
+        q, k, v = qkv.view(Bn, S, 3, H, D // H).permute(2, 0, 3, 1, 4)  # each (Bn, H, S, hd)
+        a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Bn, S, D)
     src = src + F.linear(a, attn.out_proj.weight, attn.out_proj.bias)
     src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
     src2 = F.linear(F.relu(F.linear(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)

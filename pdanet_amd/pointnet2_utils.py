@@ -208,6 +208,45 @@ class GroupRows(Function):
 group_rows = GroupRows.apply
 
 
+class GroupAttention(Function):
+    """MI355X extension: multi-head self-attention over the nsample tokens of each group, on the
+    in_proj output qkv (G, S, 3*D) laid out [q | k | v] x heads x head_dim (csrc/group_attention.hip).
+    Same math as F.scaled_dot_product_attention without mask/dropout."""
+    SUPPORTED_SEQ, SUPPORTED_HD = (8, 16, 32), (32, 64, 128)
+
+    @staticmethod
+    def supported(qkv, heads):
+        G, S, D3 = qkv.shape
+        return (qkv.is_cuda and qkv.dtype == torch.float32 and S in GroupAttention.SUPPORTED_SEQ
+                and D3 % (3 * heads) == 0 and (D3 // (3 * heads)) in GroupAttention.SUPPORTED_HD)
+
+    @staticmethod
+    @_fwd
+    def forward(ctx, qkv, heads):
+        qkv = qkv.contiguous()
+        G, S, D3 = qkv.shape
+        hd = D3 // (3 * heads)
+        out = torch.empty((G, S, heads * hd), dtype=torch.float32, device=qkv.device)
+        lse = torch.empty((G, heads, S), dtype=torch.float32, device=qkv.device)
+        pointnet2.group_attention_fwd(qkv, out, lse, G, S, heads, hd)
+        ctx.save_for_backward(qkv, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    @_bwd
+    def backward(ctx, grad_out):
+        qkv, lse = ctx.saved_tensors
+        G, S, D3 = qkv.shape
+        hd = D3 // (3 * ctx.heads)
+        grad_qkv = torch.empty_like(qkv)
+        pointnet2.group_attention_bwd(qkv, grad_out.contiguous(), lse, grad_qkv, G, S, ctx.heads, hd)
+        return grad_qkv, None
+
+
+group_attention = GroupAttention.apply
+
+
 class BallQuery(Function):
     """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
 
