@@ -13,8 +13,9 @@
 //     and the keys j in the 16 registers x 2 lane halves: the softmax over keys is then a
 //     per-lane reduction plus one cross-half exchange (no LDS, no cross-lane trees);
 //   * the k index of an MFMA is free to permute as long as A and B agree, so lane half h simply
-//     takes the contiguous half [h*hd/2, (h+1)*hd/2) of the head dimension: operands are loaded
-//     with 16-byte loads straight from the (B*np, S, 3, H, hd) in_proj output;
+//     takes the contiguous half [h*hd/2, (h+1)*hd/2) of the head dimension of its token; the
+//     32-token tiles of the (B*np, S, 3, H, hd) in_proj output are read from HBM as whole rows and
+//     turned into that lane = token layout through a wave-private LDS image (struct Tile);
 //   * P^T (resp. dS^T) in accumulator layout is directly the B operand of O^T = V^T P^T
 //     (resp. dQ^T = K^T dS^T): register t of lane half h holds key (t&3)+8(t>>2)+4h, the A operand
 //     is fetched in that key order;
@@ -40,26 +41,71 @@ struct GaPtrs {
     }
 };
 
-// contiguous half-row operand: lane (c, h) gets x[h*HD/2 + t], t = 0..HD/2-1 (zeros when !ok)
+// A 32-token x HD tile moves between HBM and the MFMA operand layout through a wave-private LDS
+// image: HBM side fully coalesced (each wave instruction covers 64/(HD/4) whole rows with 16-byte
+// lanes), operand side lane = token.  Reading operands straight from HBM with lane = token uses
+// 16 bytes of every 128-byte line per instruction and thrashes the 32 KB L1 (measured 2.1 TB/s).
+// Row stride HD+4 floats: conflict-free for ds_write_b128 (8-lane groups) and ds_read_b128.
 template <int HD>
-__device__ __forceinline__ void load_half_row(float (&dst)[HD / 2], const float* __restrict__ p, bool ok, int h) {
+struct Tile {
+    static constexpr int LD = HD + 4;
+    static constexpr int LPR = HD / 4;    // lanes per row
+    static constexpr int RPI = 64 / LPR;  // rows per wave instruction
+    static constexpr int NI = HD / 8;     // wave instructions per 32-row tile
+
+    template <class RowPtr>
+    __device__ __forceinline__ static void load(float4 (&raw)[NI], RowPtr row_ptr, int lane) {
 #pragma unroll
-    for (int q = 0; q < HD / 8; ++q) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (ok) v = *reinterpret_cast<const float4*>(p + h * (HD / 2) + 4 * q);
-        dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        for (int it = 0; it < NI; ++it) {
+            bool valid;
+            const float* p = row_ptr(it * RPI + lane / LPR, valid);  // always dereferenceable (clamped)
+            const float4 v = *reinterpret_cast<const float4*>(p + 4 * (lane % LPR));
+            raw[it] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
     }
-}
+    // registers -> LDS image -> operand: lane (c, h) gets row c, columns h*HD/2 + t
+    __device__ __forceinline__ static void to_operand(float (&dst)[HD / 2], const float4 (&raw)[NI], float* lds, int lane) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it)
+            *reinterpret_cast<float4*>(lds + (it * RPI + lane / LPR) * LD + 4 * (lane % LPR)) = raw[it];
+        const float* src = lds + (lane & 31) * LD + (lane >> 5) * (HD / 2);
+#pragma unroll
+        for (int q = 0; q < HD / 8; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(src + 4 * q);
+            dst[4 * q + 0] = v.x; dst[4 * q + 1] = v.y; dst[4 * q + 2] = v.z; dst[4 * q + 3] = v.w;
+        }
+    }
+    // accumulator of X^T[d][token] (32 columns dblk*32..) -> LDS image rows = tokens
+    __device__ __forceinline__ static void from_acc(float* lds, const f32x16& acc, int dblk, int lane) {
+        float* dst = lds + (lane & 31) * LD + dblk * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+    }
+    template <class RowPtr>
+    __device__ __forceinline__ static void store(const float* lds, RowPtr row_ptr, int lane) {
+#pragma unroll
+        for (int it = 0; it < NI; ++it) {
+            const int r = it * RPI + lane / LPR;
+            float* p = row_ptr(r);
+            const float4 v = *reinterpret_cast<const float4*>(lds + r * LD + 4 * (lane % LPR));
+            if (p) *reinterpret_cast<float4*>(p + 4 * (lane % LPR)) = v;
+        }
+    }
+};
 
 // S: tokens per group (8, 16 or 32).  A wave covers G = 32/S groups of one head.
 template <int S, int HD, bool BWD>
-__global__ __launch_bounds__(256) void group_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+__global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
                                                                float* __restrict__ out, float* __restrict__ lse,
                                                                float* __restrict__ dqkv, int64_t nb, int H, float scale) {
     constexpr int G = 32 / S;
-    constexpr int TRN = BWD ? 32 * 33 : 1;
-    __shared__ float tr[4][2][TRN];  // per wave: P and dS transposes (backward only)
+    using TL = Tile<HD>;
+    constexpr int TRN = 2 * 32 * 33;  // P and dS transposes (backward), stride 33
+    constexpr int LDSW = (BWD && TRN > 32 * TL::LD) ? TRN : 32 * TL::LD;
+    __shared__ __attribute__((aligned(16))) float lds_all[4][LDSW];  // wave-private images: no barriers
     const int w = wave_id(), lane = lane_id();
+    float* lds = lds_all[w];
     const int c = lane & 31, h2 = lane >> 5;
     const int64_t task = (int64_t)blockIdx.x * 4 + w;      // (group-block, head)
     const int head = (int)(task % H);
@@ -69,13 +115,30 @@ __global__ __launch_bounds__(256) void group_attention_kernel(const float* __res
     const int64_t bl = b0 + c / S;
     const int sl = c % S;
     const bool ok = bl < nb;
-    const float* qrow = qkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 0, head);
-    const float* krow = qkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 1, head);
-    const float* vrow = qkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 2, head);
+    // row r of the wave's 32-token tile
+    // Loads never branch on validity (a divergent branch around a load serialises load -> wait ->
+    // MFMA): rows of groups past the end read group b0's row instead and are zeroed by a select.
+    auto in_row = [&](int which) {
+        return [=](int r, bool& valid) -> const float* {
+            const int64_t b = b0 + r / S;
+            valid = b < nb;
+            return qkv + GaPtrs<HD>::qkv(S, H, valid ? b : b0, r % S, which, head);
+        };
+    };
+    auto do_row = [=](int r, bool& valid) -> const float* {
+        const int64_t b = b0 + r / S;
+        valid = b < nb;
+        return dout + GaPtrs<HD>::o(S, H, valid ? b : b0, r % S, head);
+    };
 
     float kq[HD / 2], qq[HD / 2];
-    load_half_row<HD>(kq, krow, ok, h2);  // A operand: rows j = keys
-    load_half_row<HD>(qq, qrow, ok, h2);  // B operand: cols i = queries
+    {
+        float4 rk[TL::NI], rq[TL::NI];
+        TL::load(rk, in_row(1), lane);
+        TL::load(rq, in_row(0), lane);
+        TL::to_operand(kq, rk, lds, lane);  // A operand: rows j = keys
+        TL::to_operand(qq, rq, lds, lane);  // B operand: cols i = queries
+    }
     f32x16 T;
 #pragma unroll
     for (int i = 0; i < 16; ++i) T[i] = 0.f;
@@ -112,11 +175,13 @@ __global__ __launch_bounds__(256) void group_attention_kernel(const float* __res
         }
     }
 
-    // A operand fetched in accumulator key order: x[(group of column block), key j(t,h2)][dblk*32 + c]
-    auto key_ptr = [&](int which, int t, const float* base) -> const float* {
+    // A operand fetched in accumulator key order: x[key j(t,h2)][dblk*32 + c] (128-byte rows per half wave)
+    auto key_val = [&](int which, int t, int col) -> float {
         const int j = acc_row(t, h2);
         const int64_t bj = b0 + j / S;
-        return (bj < nb) ? base + GaPtrs<HD>::qkv(S, H, bj, j % S, which, head) : nullptr;
+        const bool valid = bj < nb;
+        const float v = qkv[GaPtrs<HD>::qkv(S, H, valid ? bj : b0, j % S, which, head) + col];
+        return valid ? v : 0.f;
     };
 
     if (!BWD) {
@@ -128,24 +193,25 @@ __global__ __launch_bounds__(256) void group_attention_kernel(const float* __res
             for (int i = 0; i < 16; ++i) O[i] = 0.f;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float* vp = key_ptr(2, t, qkv);
-                const float a = vp ? vp[dblk * 32 + c] : 0.f;
-                O = __builtin_amdgcn_mfma_f32_32x32x2f32(a, P[t], O, 0, 0, 0);
+                O = __builtin_amdgcn_mfma_f32_32x32x2f32(key_val(2, t, dblk * 32 + c), P[t], O, 0, 0, 0);
             }
-            if (ok) {
-                float* op = out + GaPtrs<HD>::o(S, H, bl, sl, head) + dblk * 32 + 4 * h2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    *reinterpret_cast<float4*>(op + 8 * q) = make_float4(O[4 * q], O[4 * q + 1], O[4 * q + 2], O[4 * q + 3]);
-            }
+            TL::from_acc(lds, O, dblk, lane);
         }
+        TL::store(lds, [=](int r) -> float* {
+            const int64_t b = b0 + r / S;
+            return (b < nb) ? out + GaPtrs<HD>::o(S, H, b, r % S, head) : nullptr;
+        }, lane);
         return;
     } else {
-        const float* dorow = dout + GaPtrs<HD>::o(S, H, ok ? bl : 0, sl, head);
         // dP^T[j][i] = sum_d V[j][d] dO^T[d][i]
         float vv[HD / 2], dd[HD / 2];
-        load_half_row<HD>(vv, vrow, ok, h2);
-        load_half_row<HD>(dd, dorow, ok, h2);
+        {
+            float4 rv[TL::NI], rd[TL::NI];
+            TL::load(rv, in_row(2), lane);
+            TL::load(rd, do_row, lane);
+            TL::to_operand(vv, rv, lds, lane);
+            TL::to_operand(dd, rd, lds, lane);
+        }
         f32x16 dP;
 #pragma unroll
         for (int i = 0; i < 16; ++i) dP[i] = 0.f;
@@ -160,55 +226,71 @@ __global__ __launch_bounds__(256) void group_attention_kernel(const float* __res
         for (int r = 0; r < 16; ++r) dS[r] = P[r] * (dP[r] - delta) * scale;
 
         // transposes through LDS (stride 33: conflict-free both ways)
-        float* tp = tr[w][0];
-        float* ts = tr[w][1];
+        float* tp = lds;
+        float* ts = lds + 32 * 33;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             tp[acc_row(r, h2) * 33 + c] = P[r];    // [j][i]
             ts[acc_row(r, h2) * 33 + c] = dS[r];
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): wave-private LDS, no barrier needed
         float Pn[16], dSn[16];               // P[i(t,h2)][j = c], dS[i(t,h2)][j = c]
 #pragma unroll
         for (int t = 0; t < 16; ++t) {
             Pn[t] = tp[c * 33 + acc_row(t, h2)];
             dSn[t] = ts[c * 33 + acc_row(t, h2)];
         }
-        auto qry_o_ptr = [&](int t) -> const float* {  // dO row of query i(t,h2)
+        auto qry_o_val = [&](int t, int col) -> float {  // dO[query i(t,h2)][col]
             const int i = acc_row(t, h2);
             const int64_t bi = b0 + i / S;
-            return (bi < nb) ? dout + GaPtrs<HD>::o(S, H, bi, i % S, head) : nullptr;
+            const bool valid = bi < nb;
+            const float v = dout[GaPtrs<HD>::o(S, H, valid ? bi : b0, i % S, head) + col];
+            return valid ? v : 0.f;
         };
-        float* dq = dqkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 0, head);
-        float* dk = dqkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 1, head);
-        float* dv = dqkv + GaPtrs<HD>::qkv(S, H, ok ? bl : 0, sl, 2, head);
+        auto out_row = [&](int which) {
+            return [=](int r) -> float* {
+                const int64_t b = b0 + r / S;
+                return (b < nb) ? dqkv + GaPtrs<HD>::qkv(S, H, b, r % S, which, head) : nullptr;
+            };
+        };
+        // dQ^T = K^T dS^T
 #pragma unroll
         for (int dblk = 0; dblk < HD / 32; ++dblk) {
-            f32x16 aQ, aK, aV;
+            f32x16 acc;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { aQ[i] = 0.f; aK[i] = 0.f; aV[i] = 0.f; }
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #pragma unroll
             for (int t = 0; t < 16; ++t) {
-                const float* kp = key_ptr(1, t, qkv);   // K[j(t)][d]      -> dQ^T = K^T dS^T
-                const float* qp = key_ptr(0, t, qkv);   // Q[i(t)][d]      -> dK^T = Q^T dS
-                const float* op = qry_o_ptr(t);         // dO[i(t)][d]     -> dV^T = dO^T P
-                const float ak = kp ? kp[dblk * 32 + c] : 0.f;
-                const float aq = qp ? qp[dblk * 32 + c] : 0.f;
-                const float ao = op ? op[dblk * 32 + c] : 0.f;
-                aQ = __builtin_amdgcn_mfma_f32_32x32x2f32(ak, dS[t], aQ, 0, 0, 0);
-                aK = __builtin_amdgcn_mfma_f32_32x32x2f32(aq, dSn[t], aK, 0, 0, 0);
-                aV = __builtin_amdgcn_mfma_f32_32x32x2f32(ao, Pn[t], aV, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(key_val(1, t, dblk * 32 + c), dS[t], acc, 0, 0, 0);
             }
-            if (ok) {
-                const int off = dblk * 32 + 4 * h2;
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    *reinterpret_cast<float4*>(dq + off + 8 * q) = make_float4(aQ[4 * q], aQ[4 * q + 1], aQ[4 * q + 2], aQ[4 * q + 3]);
-                    *reinterpret_cast<float4*>(dk + off + 8 * q) = make_float4(aK[4 * q], aK[4 * q + 1], aK[4 * q + 2], aK[4 * q + 3]);
-                    *reinterpret_cast<float4*>(dv + off + 8 * q) = make_float4(aV[4 * q], aV[4 * q + 1], aV[4 * q + 2], aV[4 * q + 3]);
-                }
-            }
+            TL::from_acc(lds, acc, dblk, lane);
         }
+        TL::store(lds, out_row(0), lane);
+        // dK^T = Q^T dS
+#pragma unroll
+        for (int dblk = 0; dblk < HD / 32; ++dblk) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(key_val(0, t, dblk * 32 + c), dSn[t], acc, 0, 0, 0);
+            }
+            TL::from_acc(lds, acc, dblk, lane);
+        }
+        TL::store(lds, out_row(1), lane);
+        // dV^T = dO^T P
+#pragma unroll
+        for (int dblk = 0; dblk < HD / 32; ++dblk) {
+            f32x16 acc;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+            for (int t = 0; t < 16; ++t) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qry_o_val(t, dblk * 32 + c), Pn[t], acc, 0, 0, 0);
+            }
+            TL::from_acc(lds, acc, dblk, lane);
+        }
+        TL::store(lds, out_row(2), lane);
     }
 }
 
