@@ -13,8 +13,10 @@ Workloads (--workload):
   sampling_grouping  the sampling/grouping operators of the PDA-SSD backbone at the ONCE
                      16384-pt layer shapes: FPS, ball queries, gathers,
                      groupings -- the operators this repo implements as HIP kernels.
-  backbone           full backbone forward+backward (registered by pdanet_amd.backbone when
-                     present).
+  backbone           full backbone forward+backward (default; BASELINE's metric).
+  backbone_infer     backbone forward, eval BN, fused SA kernel (BASELINE configs[1]).
+  train_step         backbone forward+backward + grad clip + adam_onecycle step (csrc/optim.hip).
+  kitti_train_bf16   the same on the KITTI yaml with bf16 autocast (BASELINE configs[2]; use --batch 4).
 """
 import argparse
 import json
@@ -209,8 +211,8 @@ def main():
 
     scenes = args.batch * world * args.steps
     line = {
-        "metric": "scenes/sec (%d-pt ONCE, PDA-SSD %s)" % (
-            args.points, "forward+backward" if "fwd_bwd" in wl.name else ("forward" if "fwd_eval" in wl.name else "sampling/grouping ops")),
+        "metric": "scenes/sec (%d-pt %s, PDA-SSD %s)" % (
+            args.points, "KITTI" if wl.name.startswith("kitti") else "ONCE", ("forward+backward+Adam" if "adam" in wl.name else "forward+backward") if "fwd_bwd" in wl.name else ("forward" if "fwd_eval" in wl.name else "sampling/grouping ops")),
         "value": scenes / dt,
         "unit": "scenes/s",
         "n_gpus": world,

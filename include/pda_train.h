@@ -1,0 +1,35 @@
+/* pda_train.h -- C ABI of the "next rows" around the sampling/grouping path:
+ * the train-step arithmetic and the target-assignment / post-processing kernels.  Same library
+ * (libpda_pointnet2.so), same conventions as pda_pointnet2.h: device pointers, explicit stream,
+ * status return + pda_last_error(), nothing allocated, no torch types.
+ */
+#ifndef PDA_TRAIN_H
+#define PDA_TRAIN_H
+#include "pda_pointnet2.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- adam_onecycle step (tools/train_utils/optimization/fastai_optim.py:138-156 OptimWrapper.step
+ * with true_wd=True, bn_wd=True, wrapping torch.optim.Adam(betas=(mom, 0.99)); preceded by
+ * clip_grad_norm_ in tools/train_utils/train_utils.py:56) on FLAT fp32 buffers: all trained
+ * parameters, their gradients and both Adam moments each live in one contiguous allocation.
+ *
+ * pda_grad_norm: norm_out[0] = sqrt(sum g^2) in a fixed two-stage order (deterministic);
+ *   scratch holds 1024 floats.
+ * pda_adam_onecycle_step, per element:
+ *   g' = g * min(1, max_norm / (total_norm + 1e-6))         (total_norm == NULL: no clipping)
+ *   p  = p * (1 - wd * lr)                                   (decoupled decay, before Adam)
+ *   m += (g' - m) * (1 - beta1);  v = v * beta2 + (1 - beta2) * g' * g'
+ *   p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ * `step` is the 1-based Adam step count.  g is not modified. */
+int pda_grad_norm(const float *g, int64_t n, float *norm_out, float *scratch1024, pda_stream_t stream);
+int pda_adam_onecycle_step(float *p, const float *g, float *m, float *v, int64_t n, float lr,
+                           float beta1, float beta2, float eps, float wd, int step,
+                           const float *total_norm, float max_norm, pda_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,4 +1,4 @@
-"""ctypes binding of the C ABI declared in include/pda_pointnet2.h.
+"""ctypes binding of the C ABI declared in include/pda_pointnet2.h and include/pda_train.h.
 
 The library is the product: if it is missing or a symbol is absent this module raises at
 import of the first op -- there is no fallback path.
@@ -40,6 +40,9 @@ SIGNATURES = {
                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],
     "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
+    # include/pda_train.h
+    "pda_grad_norm": [_vp, ctypes.c_int64, _vp, _vp, _vp],
+    "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
 

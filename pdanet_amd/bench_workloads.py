@@ -47,6 +47,7 @@ class BackboneWorkload:
         self.name = "once16k_b%d_backbone_fwd_bwd" % batch if n_points == 16384 else \
             "once%d_b%d_backbone_fwd_bwd" % (n_points, batch)
         self.device = device
+        self.cfg_name = cfg
         self.amp = amp
         self.dtype = "bf16 dense / f32 ops" if amp else "f32"
         self.tuned = enable_tuned_gemms() if os.environ.get("PDA_NO_TUNED_GEMMS") != "1" else False
@@ -129,7 +130,7 @@ class BackboneWorkload:
         pu.pointnet2 = stub
         try:
             torch.manual_seed(1234)
-            model, _ = build_backbone("once_pda_ssd.yaml")
+            model, _ = build_backbone(self.cfg_name)
             model.train()
             pts = torch.from_numpy(self.points_np[: self.N].copy())
             nthreads = max(oracle.num_threads(), torch.get_num_threads())
@@ -191,7 +192,46 @@ class BackboneInferWorkload(BackboneWorkload):
         return base
 
 
+class TrainStepWorkload(BackboneWorkload):
+    """Forward + backward + clip_grad_norm_(10) + adam_onecycle step (pdanet_amd/optimization.py,
+    csrc/optim.hip) -- the iteration of tools/train_utils/train_utils.py:34-60 around the backbone.
+    `kitti_train_bf16` is BASELINE configs[2]: KITTI yaml, 4 scenes per GPU, bf16 autocast on the
+    dense layers (operators stay fp32)."""
+
+    OPTIM = dict(OPTIMIZER="adam_onecycle", LR=0.01, WEIGHT_DECAY=0.01, MOMS=[0.95, 0.85], PCT_START=0.4,
+                 DIV_FACTOR=10, GRAD_NORM_CLIP=10)   # once/kitti PDA-SSD.yaml OPTIMIZATION
+
+    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml", dataset="once"):
+        from . import optimization, parallel, synth
+        super().__init__(batch, n_points, device, rank, 1, amp=amp, cfg=cfg)
+        if dataset != "once":
+            self.points_np = synth.batch_points(batch, n_points, config_id=3 + 10 * rank, dist="L", dataset=dataset)
+            self.points = torch.from_numpy(self.points_np).to(device)
+        self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if amp else "")
+        self.opt = optimization.build_optimizer(self.model, self.OPTIM)     # flat buffers BEFORE DDP
+        self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.OPTIM)
+        self.ddp = parallel.wrap_ddp(self.model, device) if world > 1 else None
+        self.it = 0
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        self.sched.step(self.it)
+        self.opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+            bd = model({'batch_size': self.B, 'points': self.points})
+        loss = self.loss_of(bd)
+        loss.backward()
+        self.opt.step()
+        self.it += 1
+        return loss
+
+
 def create(name, batch, n_points, device, rank, world):
+    if name == "train_step":
+        return TrainStepWorkload(batch, n_points, device, rank, world)
+    if name == "kitti_train_bf16":
+        return TrainStepWorkload(batch, n_points, device, rank, world, amp=True, cfg="kitti_pda_ssd.yaml",
+                                 dataset="kitti")
     if name == "backbone_infer":
         return BackboneInferWorkload(batch, n_points, device, rank, world)
     if name == "backbone":

@@ -6,6 +6,7 @@
 #include <stdarg.h>
 
 #include "../../include/pda_pointnet2.h"
+#include "../../include/pda_train.h"
 
 #ifndef PDA_FP_CONTRACT
 #define PDA_FP_CONTRACT 1  // 1: fma(dz,dz,fma(dy,dy,dx*dx)) (nvcc -fmad=true); 0: uncontracted
