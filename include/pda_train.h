@@ -29,6 +29,15 @@ int pda_adam_onecycle_step(float *p, const float *g, float *m, float *v, int64_t
                            float beta1, float beta2, float eps, float wd, int step,
                            const float *total_norm, float max_norm, pda_stream_t stream);
 
+/* ---- target assignment ------------------------------------------------------------------------
+ * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
+ * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],
+ * pts (B,M,3) -> box_idx_of_points (B,M) int32 = lowest k whose box contains the point
+ * (|z-cz| <= dz/2, |local x| < dx/2 + 1e-5, |local y| < dy/2 + 1e-5 after rotating by -heading);
+ * entries of points in no box are NOT written (the caller pre-fills -1, roiaware_pool3d_utils.py:41). */
+int pda_points_in_boxes(const float *boxes, const float *pts, int32_t *box_idx_of_points, int b, int t,
+                        int m, pda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

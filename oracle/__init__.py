@@ -32,4 +32,5 @@ from .binding import (  # noqa: F401
     three_interpolate_grad_wrapper,
     chamfer_forward,
     chamfer_backward,
+    points_in_boxes_gpu,
 )

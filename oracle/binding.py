@@ -142,3 +142,11 @@ def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1,
                                               _f(gradxyz1, (b, n, 3)), _f(gradxyz2, (b, m, 3)),
                                               _f(graddist1, (b, n)), _f(graddist2, (b, m)),
                                               _i(idx1, (b, n)), _i(idx2, (b, m)))
+
+
+def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
+    """roiaware_pool3d.cpp:98-118 (argument order of the extension: boxes, points, out)."""
+    b, t, _ = boxes.shape
+    m = pts.shape[1]
+    return _lib().pda_oracle_points_in_boxes(b, t, m, _f(boxes, (b, t, 7)), _f(pts, (b, m, 3)),
+                                             _i(box_idx_of_points, (b, m)))

@@ -423,3 +423,42 @@ PDA_EXPORT int pda_oracle_chamfer_backward(int b, int n, int m, const float *xyz
     nm_distance_grad(b, m, xyz2, n, xyz1, graddist2, idx2, gradxyz2, gradxyz1);
     return 1;
 }
+
+/* ---- points_in_boxes ------------------------------------------------------
+ * roiaware_pool3d_kernel.cu:16-36 (lidar_to_local_coords, check_pt_in_box3d) and :313-336
+ * (points_in_boxes_kernel): the FIRST box k (ascending) that contains the point, else the caller's -1.
+ * The comparisons against dz/2.0 and d/2.0 + MARGIN are double comparisons in the reference (the
+ * literals are double), kept so here.  cos/sin: the CUDA code calls cosf/sinf, whose results differ
+ * by an ulp or two between CUDA, glibc and OCML; oracle and HIP kernel both use the correctly rounded
+ * single-precision value (computed in double), which each of those approximates.  Points closer to a
+ * box face than that rounding noise (~1e-7 of the offset) may classify differently from a CUDA run. */
+PDA_EXPORT int pda_oracle_points_in_boxes(int b, int t, int m, const float *boxes, const float *pts,
+                                          int *box_idx_of_points) {
+    const float MARGIN = 1e-5f;
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < b; ++i)
+        for (int j = 0; j < m; ++j) {
+            const float *pt = pts + ((size_t)i * m + j) * 3;
+            const float x = pt[0], y = pt[1], z = pt[2];
+            for (int k = 0; k < t; ++k) {
+                const float *bx = boxes + ((size_t)i * t + k) * 7;
+                const float cx = bx[0], cy = bx[1], cz = bx[2], dx = bx[3], dy = bx[4], dz = bx[5], rz = bx[6];
+                if ((double)fabsf(z - cz) > (double)dz / 2.0) continue;
+                const float cosa = (float)cos((double)(-rz)), sina = (float)sin((double)(-rz));
+                const float sx = x - cx, sy = y - cy;
+#if PDA_ORACLE_CONTRACT
+                const float lx = fmaf(sx, cosa, sy * (-sina));
+                const float ly = fmaf(sx, sina, sy * cosa);
+#else
+                const float lx = sx * cosa + sy * (-sina);
+                const float ly = sx * sina + sy * cosa;
+#endif
+                if (((double)fabsf(lx) < (double)dx / 2.0 + (double)MARGIN) &
+                    ((double)fabsf(ly) < (double)dy / 2.0 + (double)MARGIN)) {
+                    box_idx_of_points[(size_t)i * m + j] = k;
+                    break;
+                }
+            }
+        }
+    return 1;
+}

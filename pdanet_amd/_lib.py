@@ -42,6 +42,7 @@ SIGNATURES = {
     "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
     # include/pda_train.h
     "pda_grad_norm": [_vp, ctypes.c_int64, _vp, _vp, _vp],
+    "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]

@@ -1,0 +1,389 @@
+"""IASSD_Head: the detection head, target assignment and losses of PDA-SSD.
+
+Follows pcdet/models/dense_heads/IASSD_head.py (forward :1343-1399, assign_targets :279-468,
+assign_stack_targets_IASSD :132-277, get_loss :470-521 and the loss terms it selects for the two
+PDA-SSD yamls) and point_head_template.py:36-47,193-207.  Same parameters / state-dict keys
+(`cls_center_layers`, `box_center_layers`), same loss values.
+
+MI355X-first execution.  The reference walks the scenes in a Python loop, compacts every tensor with
+boolean masks (`x[mask]`, `.unique()`, one `.item()` per logged scalar) and so synchronises the host
+dozens of times per step.  Here all scenes are assigned by one batched `points_in_boxes` launch per
+(point set, box set) and every loss is a MASKED reduction over dense `(B*N, ...)` tensors -- no
+compaction, no host synchronisation anywhere between the backbone and `loss.backward()`; `tb_dict`
+holds device scalars (call `.item()` on them only when logging).  A mean over compacted rows equals
+the masked sum divided by the mask count, so the values are the reference's up to fp32 summation
+order.  Requirements inherited from IASSD_Backbone: every scene contributes the same number of
+points to a layer, stored scene-major.
+
+Not reproduced: the Chamfer distance between each ctr-aware layer's samples and a top-k "ideal"
+sample set, which the reference computes inside gauss_fun_once_topk_GT_add_same_size (:967-1043) but
+only LOGS (`tb_dict['CD_loss']`, :722 has the `+0.8*` term commented out); the unused
+clusterContrastLoss member (:47); loss branches no PDA-SSD yaml selects (ver1 vote loss, IoU head,
+PointResidualCoder, focal / binary-CE variants).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import box_coder_utils, box_utils, loss_utils, roiaware_pool3d_utils
+
+
+def _get(cfg, key, default=None):
+    return cfg.get(key, default) if hasattr(cfg, "get") else getattr(cfg, key, default)
+
+
+class IASSD_Head(nn.Module):  # noqa: N801
+    def __init__(self, num_class, input_channels, model_cfg, predict_boxes_when_training=False, **kwargs):
+        super().__init__()
+        self.model_cfg, self.num_class = model_cfg, num_class
+        self.predict_boxes_when_training = predict_boxes_when_training
+        target_cfg = model_cfg["TARGET_CONFIG"]
+        if target_cfg["BOX_CODER"] != "PointResidual_BinOri_Coder":
+            raise NotImplementedError(target_cfg["BOX_CODER"])
+        self.box_coder = box_coder_utils.PointResidual_BinOri_Coder(**target_cfg["BOX_CODER_CONFIG"])
+        detector_dim = _get(model_cfg, "INPUT_DIM", input_channels)
+        self.cls_center_layers = self.make_fc_layers(model_cfg["CLS_FC"], detector_dim, num_class)
+        self.box_center_layers = self.make_fc_layers(model_cfg["REG_FC"], detector_dim, self.box_coder.code_size)
+        if _get(model_cfg, "IOU_FC") is not None:
+            raise NotImplementedError("IOU_FC head (not used by PDA-SSD.yaml)")
+        self.build_losses(model_cfg["LOSS_CONFIG"])
+        self.forward_ret_dict = None
+
+    # point_head_template.py:36-47
+    @staticmethod
+    def make_fc_layers(fc_cfg, input_channels, output_channels):
+        layers, c_in = [], input_channels
+        for c in fc_cfg:
+            layers.extend([nn.Linear(c_in, c, bias=False), nn.BatchNorm1d(c), nn.ReLU()])
+            c_in = c
+        layers.append(nn.Linear(c_in, output_channels, bias=True))
+        return nn.Sequential(*layers)
+
+    # IASSD_head.py:69-131, the configured subset
+    def build_losses(self, losses_cfg):
+        for key in ("LOSS_CLS", "LOSS_INS"):
+            if not str(_get(losses_cfg, key, "WeightedCrossEntropy")).startswith("WeightedCrossEntropy"):
+                raise NotImplementedError("%s = %s" % (key, losses_cfg[key]))
+        if losses_cfg["LOSS_REG"] != "WeightedSmoothL1Loss":
+            raise NotImplementedError(losses_cfg["LOSS_REG"])
+        self.cls_loss_func = loss_utils.WeightedClassificationLoss()
+        self.ins_loss_func = loss_utils.WeightedClassificationLoss()
+        self.reg_loss_func = loss_utils.WeightedSmoothL1Loss(
+            code_weights=_get(losses_cfg["LOSS_WEIGHTS"], "code_weights"), **_get(losses_cfg, "LOSS_REG_CONFIG", {}))
+
+    # ---- target assignment ---------------------------------------------------------------------
+    def assign_stack_targets_IASSD(self, points, gt_boxes, extend_gt_boxes=None, ret_box_labels=False,  # noqa: N802
+                                   set_ignore_flag=True, use_ex_gt_assign=False, fg_pc_ignore=False,
+                                   binary_label=False):
+        """IASSD_head.py:132-277 for all scenes at once.
+
+        points (B*N, 4) [bs_idx, x, y, z] scene-major, gt_boxes / extend_gt_boxes (B, T, 8).
+        Returns dense per-point tensors:
+          point_cls_labels (B*N) long: 0 background, -1 ignored, else the class of the box
+          point_box_labels (B*N, 8) box-coder targets (0 where not foreground) or None
+          box_idxs_labels  (B*N) long box index used for the assignment (-1: none)
+          gt_box_of_points (B*N, 8) = gt_boxes[scene][box index] (index -1 wraps to the last row, as in
+                           the reference's advanced indexing)
+        The reference's compacted 'gt_box_of_fg_points' is gt_box_of_points[point_cls_labels > 0].
+        """
+        assert points.dim() == 2 and points.shape[1] == 4 and gt_boxes.dim() == 3 and gt_boxes.shape[2] == 8
+        B, T = gt_boxes.shape[0], gt_boxes.shape[1]
+        assert points.shape[0] % B == 0, "scenes must contribute equally many points"
+        xyz = points[:, 1:4].reshape(B, -1, 3).contiguous()
+        N = xyz.shape[1]
+        in_box = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, gt_boxes[:, :, 0:7].contiguous()).long()
+        box_fg = in_box >= 0
+        labels = torch.zeros_like(in_box)
+        if use_ex_gt_assign:                                                          # :190-205
+            in_ext = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, extend_gt_boxes[:, :, 0:7].contiguous()).long()
+            ext_fg = in_ext >= 0
+            idx = torch.where(box_fg, in_box, in_ext)                                 # instance points keep their box
+            if fg_pc_ignore:
+                fg = ext_fg ^ box_fg
+                idx = torch.where(in_box != -1, torch.full_like(idx, -1), idx)
+            else:
+                fg = ext_fg
+        elif set_ignore_flag:                                                         # :207-217
+            in_ext = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, extend_gt_boxes[:, :, 0:7].contiguous()).long()
+            fg, idx = box_fg, in_box
+            labels = torch.where(fg ^ (in_ext >= 0), torch.full_like(labels, -1), labels)
+        else:
+            raise NotImplementedError
+        gt_of_pts = torch.gather(gt_boxes, 1, torch.where(idx < 0, idx + T, idx).unsqueeze(-1).expand(B, N, 8))
+        cls_of_box = torch.ones_like(labels) if (self.num_class == 1 or binary_label) else gt_of_pts[..., -1].long()
+        labels = torch.where(fg, cls_of_box, labels)                                  # :231
+        fg = fg & (labels != 0)                                                       # :237-239
+        box_labels = None
+        if ret_box_labels:                                                            # :246-259
+            enc = self.box_coder.encode_torch(gt_of_pts.reshape(B * N, 8)[:, :-1], xyz.reshape(B * N, 3),
+                                              gt_classes=gt_of_pts.reshape(B * N, 8)[:, -1].long().clamp(min=1))
+            box_labels = torch.where(fg.reshape(-1, 1), enc, torch.zeros_like(enc))
+        return {'point_cls_labels': labels.reshape(-1), 'point_box_labels': box_labels,
+                'box_idxs_labels': idx.reshape(-1), 'gt_box_of_points': gt_of_pts.reshape(B * N, 8)}
+
+    def assign_targets(self, input_dict):
+        """IASSD_head.py:279-468 (TARGET_CONFIG of the PDA-SSD yamls: INS_AWARE_ASSIGN, ASSIGN_METHOD extend_gt)."""
+        target_cfg = self.model_cfg["TARGET_CONFIG"]
+        gt_boxes = input_dict['gt_boxes']
+        if gt_boxes.shape[-1] == 10:
+            gt_boxes = torch.cat((gt_boxes[..., 0:7], gt_boxes[..., -1:]), dim=-1)
+        B = input_dict['batch_size']
+        self._bs, self._num_boxes = B, gt_boxes.shape[1]
+        if _get(target_cfg, 'EXTRA_WIDTH', False):
+            raise NotImplementedError("TARGET_CONFIG.EXTRA_WIDTH (enlarge_box3d_for_class)")
+
+        def enlarge(width):
+            return box_utils.enlarge_box3d(gt_boxes.view(-1, gt_boxes.shape[-1]), extra_width=width).view(B, -1, gt_boxes.shape[-1])
+
+        out = {}
+        t = self.assign_stack_targets_IASSD(input_dict['centers'].detach(), gt_boxes, enlarge(target_cfg["GT_EXTRA_WIDTH"]),
+                                            set_ignore_flag=True, ret_box_labels=True)
+        out['center_cls_labels'], out['center_box_labels'] = t['point_cls_labels'], t['point_box_labels']
+        out['center_gt_box_of_points'] = t['gt_box_of_points']
+        if _get(target_cfg, 'INS_AWARE_ASSIGN', False):
+            preds = input_dict['sa_ins_preds']
+            ext = enlarge([0.5, 0.5, 0.5])
+            first = self.assign_stack_targets_IASSD(input_dict['encoder_coords'][0].reshape(-1, 4).detach(), gt_boxes, ext,
+                                                    set_ignore_flag=True)            # :329-343
+            out['get_origin_class_label'] = [first['point_cls_labels']]
+            labels, boxes, coords, idxs = [], [], [], []
+            for i in range(1, len(preds)):                                            # :347-385
+                sa_xyz = input_dict['encoder_coords'][i]
+                t = self.assign_stack_targets_IASSD(sa_xyz.reshape(-1, sa_xyz.shape[-1]).detach(), gt_boxes, ext,
+                                                    set_ignore_flag=(i == 1), use_ex_gt_assign=(i >= 2))
+                coords.append(sa_xyz); labels.append(t['point_cls_labels'])
+                boxes.append(t['gt_box_of_points']); idxs.append(t['box_idxs_labels'])
+            out.update(sa_ins_labels=labels, sa_xyz_coords=coords, sa_gt_box_of_points=boxes, sa_box_idxs_labels=idxs)
+        extra = _get(target_cfg, 'ASSIGN_METHOD')
+        if extra is not None:
+            if extra["NAME"] != 'extend_gt':
+                raise NotImplementedError(extra["NAME"])
+            pts = input_dict['centers_origin' if _get(extra, 'ASSIGN_TYPE', 'centers') == 'centers_origin' else 'centers'].detach()
+            t = self.assign_stack_targets_IASSD(pts, gt_boxes, enlarge(extra["EXTRA_WIDTH"]), set_ignore_flag=True,
+                                                ret_box_labels=True, use_ex_gt_assign=True,
+                                                fg_pc_ignore=extra["FG_PC_IGNORE"])  # :397-411
+            out['center_origin_cls_labels'] = t['point_cls_labels']
+            out['center_origin_box_idxs_of_pts'] = t['box_idxs_labels']
+            out['gt_box_of_center_origin'] = t['gt_box_of_points']
+        return out
+
+    # ---- forward -------------------------------------------------------------------------------
+    def generate_predicted_boxes(self, points, point_cls_preds, point_box_preds):  # point_head_template.py:193-207
+        _, pred_classes = point_cls_preds.max(dim=-1)
+        return point_cls_preds, self.box_coder.decode_torch(point_box_preds, points, pred_classes + 1)
+
+    def forward(self, batch_dict):
+        feats, centers = batch_dict['centers_features'], batch_dict['centers']
+        cls_preds = self.cls_center_layers(feats)
+        box_preds = self.box_center_layers(feats)
+        ret = {'center_cls_preds': cls_preds, 'center_box_preds': box_preds, 'ctr_offsets': batch_dict['ctr_offsets'],
+               'centers': centers, 'centers_origin': batch_dict['centers_origin'],
+               'sa_ins_preds': batch_dict['sa_ins_preds'], 'sample_list_id': batch_dict.get('sample_list_id'),
+               'box_iou3d_preds': None}
+        if self.training:
+            ret.update(self.assign_targets(batch_dict))
+        loss_cfg = self.model_cfg["LOSS_CONFIG"]
+        if (not self.training or self.predict_boxes_when_training or _get(loss_cfg, "CORNER_LOSS_REGULARIZATION", False)
+                or _get(loss_cfg, "CENTERNESS_REGULARIZATION", False) or _get(loss_cfg, "IOU3D_REGULARIZATION", False)):
+            point_cls_preds, point_box_preds = self.generate_predicted_boxes(centers[:, 1:4], cls_preds, box_preds)
+            batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = point_cls_preds, point_box_preds
+            batch_dict['box_iou3d_preds'] = None
+            batch_dict['batch_index'] = centers[:, 0]
+            batch_dict['cls_preds_normalized'] = False
+            ret['point_box_preds'] = point_box_preds
+        self.forward_ret_dict = ret
+        return batch_dict
+
+    # ---- losses (masked-dense forms of IASSD_head.py:470-521 and the terms it calls) -----------
+    def get_loss(self, tb_dict=None):
+        tb_dict = {} if tb_dict is None else tb_dict
+        cfg, tcfg = self.model_cfg["LOSS_CONFIG"], self.model_cfg["TARGET_CONFIG"]
+        am = _get(tcfg, 'ASSIGN_METHOD')
+        if am is not None and _get(am, 'ASSIGN_TYPE') == 'centers_origin':
+            kind = _get(cfg, 'LOSS_VOTE_TYPE', 'none')
+            if kind == 'ver2':
+                vote = self.get_contextual_vote_loss_ver2(tb_dict)
+            elif kind == 'none':
+                vote = self.get_contextual_vote_loss(tb_dict)
+            else:
+                raise NotImplementedError("LOSS_VOTE_TYPE %s" % kind)
+        else:
+            raise NotImplementedError("vote loss on 'centers' assignment (get_vote_loss_loss)")
+        sa = self.get_sa_ins_layer_loss(tb_dict) if _get(cfg, 'LOSS_INS') is not None else 0
+        cls = self.get_center_cls_layer_loss(tb_dict)
+        box = self.get_center_box_binori_layer_loss(tb_dict)
+        corner = self.get_corner_layer_loss(tb_dict) if _get(cfg, 'CORNER_LOSS_REGULARIZATION', False) else 0
+        return vote + cls + box + corner + sa, tb_dict
+
+    def _weights(self):
+        return self.model_cfg["LOSS_CONFIG"]["LOSS_WEIGHTS"]
+
+    def get_contextual_vote_loss_ver2(self, tb_dict):
+        """:579-619.  Per GT instance (scene, box): [sum smooth-L1(vote, box centre) + 0.5 * sum
+        smooth-L1(vote, mean vote of the instance)] / #points, then the mean over instances."""
+        r = self.forward_ret_dict
+        idx, gt = r['center_origin_box_idxs_of_pts'], r['gt_box_of_center_origin']
+        pred = r['centers_origin'][:, 1:4] + r['ctr_offsets'][:, 1:4]
+        B, S = self._bs, self._num_boxes                      # segment = scene * (boxes per scene) + box index
+        scene = torch.arange(B, device=idx.device).repeat_interleave(idx.shape[0] // B)
+        valid = idx >= 0
+        seg = torch.where(valid, scene * S + idx, torch.full_like(idx, B * S))       # dump bin for unassigned points
+        ones = valid.to(pred.dtype)
+        cnt = torch.zeros(B * S + 1, device=pred.device, dtype=pred.dtype).index_add_(0, seg, ones)
+        mean = torch.zeros(B * S + 1, 3, device=pred.device, dtype=pred.dtype).index_add_(0, seg, pred * ones[:, None])
+        mean = mean / cnt.clamp(min=1.0)[:, None]
+        l_gt = F.smooth_l1_loss(pred, gt[:, 0:3], reduction='none').sum(-1)
+        l_mean = F.smooth_l1_loss(pred, mean[seg], reduction='none').sum(-1)
+        per_pt = torch.where(valid, l_gt + 0.5 * l_mean, torch.zeros_like(l_gt))
+        per_ins = torch.zeros(B * S + 1, device=pred.device, dtype=pred.dtype).index_add_(0, seg, per_pt) / cnt.clamp(min=1.0)
+        present = (cnt[:-1] > 0).to(pred.dtype)
+        loss = (per_ins[:-1] * present).sum() / present.sum().clamp(min=1.0)
+        loss = loss * self._weights()['vote_weight']
+        tb_dict['vote_loss_ver2'] = loss.detach()
+        return loss
+
+    def get_contextual_vote_loss(self, tb_dict):
+        """:525-548.  Mean over the classes present of the mean smooth-L1 between votes and box centres."""
+        r = self.forward_ret_dict
+        labels, gt = r['center_origin_cls_labels'], r['gt_box_of_center_origin']
+        pred = r['centers_origin'][:, 1:4] + r['ctr_offsets'][:, 1:4]
+        l = F.smooth_l1_loss(pred, gt[:, 0:3], reduction='none').sum(-1)
+        total, present = 0, 0
+        for c in range(1, self.num_class + 1):
+            m = labels == c
+            n = m.sum()
+            total = total + torch.where(m, l, torch.zeros_like(l)).sum() / (3.0 * n.clamp(min=1))
+            present = present + (n > 0).to(l.dtype)
+        loss = total / present * self._weights()['vote_weight']
+        tb_dict['center_origin_loss_reg'] = loss.detach()
+        return loss
+
+    @staticmethod
+    def _one_hot_targets(preds, labels, num_class):
+        one_hot = preds.new_zeros(*labels.shape, num_class + 1)
+        one_hot.scatter_(-1, (labels * (labels >= 0).long()).unsqueeze(-1).long(), 1.0)
+        return one_hot[..., 1:]
+
+    @staticmethod
+    def _cls_weights(labels):
+        positives = labels > 0
+        w = ((labels == 0) * 1.0 + 1.0 * positives).float()
+        n = positives.sum(dim=0).float()
+        return w / torch.clamp(n, min=1.0), n
+
+    def get_center_cls_layer_loss(self, tb_dict):
+        """:637-664."""
+        r = self.forward_ret_dict
+        labels = r['center_cls_labels'].view(-1)
+        preds = r['center_cls_preds'].view(-1, self.num_class)
+        w, n = self._cls_weights(labels)
+        targets = self._one_hot_targets(preds, labels, self.num_class)
+        if self.model_cfg["LOSS_CONFIG"]["CENTERNESS_REGULARIZATION"]:
+            targets = targets * self.generate_center_ness_mask().unsqueeze(-1)
+        loss = self.cls_loss_func(preds, targets, weights=w).mean(dim=-1).sum() * self._weights()['point_cls_weight']
+        tb_dict.update(center_loss_cls=loss.detach(), center_pos_num=n)
+        return loss
+
+    def generate_center_ness_mask(self):
+        """:795-817: cube root of prod_axes min(d-, d+)/max(d-, d+) of the centre inside its box."""
+        r = self.forward_ret_dict
+        pos = r['center_cls_labels'] > 0
+        gt = r['center_gt_box_of_points']
+        off = r['centers'][:, 1:4].detach() - gt[:, 0:3]
+        off = box_utils.rotate_points_along_z(off.unsqueeze(1), -gt[:, 6]).squeeze(1)
+        template = box_utils.const_tensor(gt, 'centerness', ([1, 1, 1], [-1, -1, -1])) / 2
+        margin = gt[:, None, 3:6].repeat(1, 2, 1) * template[None, :, :]
+        dist = margin - off[:, None, :].repeat(1, 2, 1)
+        d0, d1 = dist[:, 0, :], -dist[:, 1, :]
+        c = torch.min(d0, d1) / torch.max(d0, d1)
+        c = torch.pow(torch.clamp(c[:, 0] * c[:, 1] * c[:, 2], min=1e-6), 1 / 3)
+        return torch.where(pos, c, torch.zeros_like(c))
+
+    def sa_gaussian_masks(self):
+        """The soft labels of gauss_fun_once_topk_GT_add_same_size (:889-963): exp(-0.5 |S d|^2) with d
+        the point's offset in its box frame and S = diag(4/(w^2+l^2), 4/(w^2+h^2), 4/(h^2+l^2)),
+        scaled x4 / x6 / x5 for classes 1 / 2 / 3."""
+        r = self.forward_ret_dict
+        masks = []
+        for labels, gt, coords in zip(r['sa_ins_labels'], r['sa_gt_box_of_points'], r['sa_xyz_coords']):
+            pos = labels > 0
+            xyz = coords.reshape(-1, coords.shape[-1])[:, 1:4].detach()
+            off = box_utils.rotate_points_along_z((xyz - gt[:, 0:3]).unsqueeze(1), -gt[:, 6]).squeeze(1)
+            w, l, h, cls = gt[:, 3], gt[:, 4], gt[:, 5], gt[:, -1]
+            covs = []
+            for c in (4 / (w ** 2 + l ** 2), 4 / (w ** 2 + h ** 2), 4 / (h ** 2 + l ** 2)):
+                c = torch.where(cls == 1, c * 4, c)
+                c = torch.where(cls == 2, c * 6, c)
+                c = torch.where(cls == 3, c * 5, c)
+                covs.append(c)
+            v = off * torch.stack(covs, dim=-1)
+            hm = torch.exp(-0.5 * (v * v).sum(-1))
+            masks.append(torch.where(pos, hm, torch.zeros_like(hm)))
+        return masks
+
+    def get_sa_ins_layer_loss(self, tb_dict):
+        """:668-735."""
+        r = self.forward_ret_dict
+        labels_l, preds_l = r['sa_ins_labels'], r['sa_ins_preds']
+        masks = self.sa_gaussian_masks()
+        methods = self.model_cfg["LOSS_CONFIG"]["SAMPLE_METHOD_LIST"]
+        ws = _get(self._weights(), 'ins_aware_weight', [1] * len(labels_l))
+        total, ignore = 0, 0
+        for i in range(len(labels_l)):
+            if len(preds_l[i]) == 0:
+                ignore += 1
+                continue
+            preds = preds_l[i][..., 1:].reshape(-1, self.num_class)
+            labels = labels_l[i].view(-1)
+            w, n = self._cls_weights(labels)
+            targets = self._one_hot_targets(preds, labels, self.num_class)
+            if 'ctr' in methods[i + 1][0]:
+                targets = targets * masks[i].unsqueeze(-1)
+            li = self.ins_loss_func(preds, targets, weights=w).mean(dim=-1).sum() * ws[i]
+            total = total + li
+            tb_dict['sa%d_loss_ins' % i], tb_dict['sa%d_pos_num' % i] = li.detach(), n
+        total = total / (len(labels_l) - ignore)
+        tb_dict['sa_loss_ins'] = tb_dict['sa_loss_ins_all'] = total.detach()
+        return total
+
+    def get_center_box_binori_layer_loss(self, tb_dict):
+        """:1239-1281."""
+        r = self.forward_ret_dict
+        pos = r['center_cls_labels'] > 0
+        labels, preds = r['center_box_labels'], r['center_box_preds']
+        w = pos.float()
+        w = w / torch.clamp(pos.sum().float(), min=1.0)
+        loss_xyzwhl = self.reg_loss_func(preds[None, :, :6], labels[None, :, :6], weights=w[None]).sum()
+        nb = self.box_coder.bin_size
+        bin_id, bin_res = preds[:, 6:6 + nb], preds[:, 6 + nb:]
+        lab_id, lab_res = labels[:, 6].long(), labels[:, 7]
+        loss_cls = (F.cross_entropy(bin_id.contiguous(), lab_id.contiguous(), reduction='none') * w).sum()
+        res = torch.sum(bin_res * F.one_hot(lab_id, nb).float(), dim=-1)
+        loss_res = torch.sum(F.smooth_l1_loss(res, lab_res) * w)        # mean over ALL points times sum(w), as written (:1268-1269)
+        lw = self._weights()
+        loss_cls = loss_cls * _get(lw, 'dir_weight', 1.0)
+        loss = (loss_xyzwhl + loss_res + loss_cls) * lw['point_box_weight']
+        tb_dict.update(center_loss_box=loss.detach(), center_loss_box_xyzwhl=loss_xyzwhl.detach(),
+                       center_loss_box_ori_bin=loss_cls.detach(), center_loss_box_ori_res=loss_res.detach())
+        return loss
+
+    def get_corner_layer_loss(self, tb_dict):
+        """:1307-1321."""
+        r = self.forward_ret_dict
+        pos = r['center_cls_labels'] > 0
+        per_pt = loss_utils.get_corner_loss_lidar(r['point_box_preds'][:, 0:7], r['center_gt_box_of_points'][:, 0:7])
+        loss = torch.where(pos, per_pt, torch.zeros_like(per_pt)).sum() / pos.sum()
+        loss = loss * self._weights()['corner_weight']
+        tb_dict['corner_loss_reg'] = loss.detach()
+        return loss
+
+    def compact_targets(self):
+        """The reference's compacted views (host-synchronising; for inspection and tests only)."""
+        r = self.forward_ret_dict
+        out = {'center_gt_box_of_fg_points': r['center_gt_box_of_points'][r['center_cls_labels'] > 0]}
+        if 'sa_ins_labels' in r:
+            out['sa_gt_box_of_fg_points'] = [g[l > 0] for g, l in zip(r['sa_gt_box_of_points'], r['sa_ins_labels'])]
+        if 'center_origin_cls_labels' in r:
+            out['center_origin_gt_box_of_fg_points'] = r['gt_box_of_center_origin'][r['center_origin_cls_labels'] > 0]
+        return out

@@ -1,0 +1,121 @@
+"""IASSD_Head against tests/golden/head_{once,kitti}.npz, which
+tests/golden/make_head_golden.py produced by running the REFERENCE head on CPU.
+
+CPU leg: this repo's head with `points_in_boxes_gpu` swapped for the CPU oracle (host logic only).
+GPU leg: the product path (HIP points_in_boxes, everything on the device, no host sync)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from detweights import fill_deterministic  # noqa: E402
+from head_inputs import synth_inputs  # noqa: E402
+
+
+def _prepare(tag, device):
+    from pdanet_amd import config
+    from pdanet_amd.iassd_head import IASSD_Head
+    gold = np.load(os.path.join(HERE, "golden", "head_%s.npz" % tag))
+    cfg = config.load_yaml("%s_pda_ssd.yaml" % tag)
+    nc = int(gold["num_class"])
+    assert nc == len(cfg.CLASS_NAMES)
+    head = IASSD_Head(num_class=nc, input_channels=512, model_cfg=cfg.MODEL.POINT_HEAD)
+    fill_deterministic(head, salt="head.")
+    head = head.to(device).train()
+    inp = synth_inputs(nc, int(gold["seed"]))
+    t = lambda a: torch.from_numpy(a.copy()).to(device)  # noqa: E731
+    B = inp["gt_boxes"].shape[0]
+    feats = t(inp["feats"]).requires_grad_(True)
+    offs = t(inp["offsets"].reshape(-1, 3)).requires_grad_(True)
+    bidx = t(inp["centers"].reshape(-1, 4)[:, :1])
+    sa_raw = [None if p is None else t(p).requires_grad_(True) for p in inp["sa_preds"]]
+    sa_preds = [[] if p is None else torch.cat([t(inp["coords"][i + 1][..., :1]), p], dim=-1) for i, p in enumerate(sa_raw)]
+    bd = {"batch_size": B, "gt_boxes": t(inp["gt_boxes"]), "centers_features": feats,
+          "centers": t(inp["centers"].reshape(-1, 4)), "centers_origin": t(inp["origin"].reshape(-1, 4)),
+          "ctr_offsets": torch.cat([bidx, offs], dim=1), "sa_ins_preds": sa_preds,
+          "encoder_coords": [t(c) for c in inp["coords"]], "sample_list_id": []}
+    leaves = dict(feats=feats, offsets=offs, **{"sa%d" % i: p for i, p in enumerate(sa_raw) if p is not None})
+    return gold, head, bd, leaves
+
+
+def _step(head, bd):
+    head(bd)
+    loss, tb = head.get_loss()
+    loss.backward()
+    return loss, tb
+
+
+def _run(tag, device):
+    gold, head, bd, leaves = _prepare(tag, device)
+    loss, tb = _step(head, bd)
+    return gold, head, loss, tb, {k: v.grad for k, v in leaves.items()}
+
+
+def _check(gold, head, loss, tb, grads):
+    n = lambda x: x.detach().cpu().numpy()  # noqa: E731
+    r = head.forward_ret_dict
+    # target assignment: integer results exact
+    for k in ("center_cls_labels", "center_origin_cls_labels", "center_origin_box_idxs_of_pts"):
+        assert np.array_equal(n(r[k]), gold["ret/" + k]), k
+    assert np.array_equal(n(r["get_origin_class_label"][0]), gold["ret/origin_class_label"])
+    for i, l in enumerate(r["sa_ins_labels"]):
+        assert np.array_equal(n(l), gold["ret/sa_ins_labels/%d" % i])
+    np.testing.assert_allclose(n(r["center_gt_box_of_points"]), gold["ret/center_gt_box_of_points"], atol=0)
+    np.testing.assert_allclose(n(r["gt_box_of_center_origin"]), gold["ret/gt_box_of_center_origin"], atol=0)
+    np.testing.assert_allclose(n(r["center_box_labels"]), gold["ret/center_box_labels"], rtol=1e-5, atol=1e-6)
+    comp = head.compact_targets()
+    np.testing.assert_allclose(n(comp["center_gt_box_of_fg_points"]), gold["ret/center_gt_box_of_fg_points"], atol=1e-6)
+    np.testing.assert_allclose(n(comp["center_origin_gt_box_of_fg_points"]), gold["ret/center_origin_gt_box_of_fg_points"], atol=0)
+    for i, gbox in enumerate(comp["sa_gt_box_of_fg_points"]):
+        np.testing.assert_allclose(n(gbox), gold["ret/sa_gt_box_of_fg_points/%d" % i], atol=0)
+    # predictions, soft labels
+    np.testing.assert_allclose(n(r["center_cls_preds"]), gold["ret/center_cls_preds"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(n(r["point_box_preds"]), gold["ret/point_box_preds"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(n(head.generate_center_ness_mask()), gold["ret/centerness"], rtol=1e-4, atol=1e-6)
+    for i, m in enumerate(head.sa_gaussian_masks()):
+        np.testing.assert_allclose(n(m), gold["ret/sa_gauss/%d" % i], rtol=1e-4, atol=1e-6)
+    # every logged loss term except the reference's logged-only CD metric, then the total and gradients
+    for k in gold.files:
+        if k.startswith("tb/") and k != "tb/CD_loss":
+            assert k[3:] in tb, k
+            assert float(tb[k[3:]]) == pytest.approx(float(gold[k]), rel=2e-5, abs=1e-6), k
+    assert float(loss) == pytest.approx(float(gold["loss"]), rel=2e-5)
+    for k, g in grads.items():
+        ref = gold["grad/" + k]
+        assert np.abs(n(g) - ref).max() <= 2e-5 * max(1.0, np.abs(ref).max()), k
+
+
+@pytest.mark.parametrize("tag", ["once", "kitti"])
+def test_head_host_logic_matches_reference_cpu(tag, oracle, monkeypatch):
+    from pdanet_amd import roiaware_pool3d_utils as ru
+
+    def pib(points, boxes):
+        out = np.full(points.shape[:2], -1, np.int32)
+        oracle.points_in_boxes_gpu(boxes.contiguous().numpy(), points.contiguous().numpy(), out)
+        return torch.from_numpy(out)
+    monkeypatch.setattr(ru, "points_in_boxes_gpu", pib)
+    _check(*_run(tag, "cpu"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["once", "kitti"])
+def test_head_matches_reference_gpu(tag):
+    _check(*_run(tag, "cuda"))
+
+
+@pytest.mark.gpu
+def test_loss_path_has_no_host_sync():
+    """forward -> targets -> losses -> backward must not synchronise (the reference syncs dozens of times)."""
+    gold, head, bd, leaves = _prepare("once", "cuda")
+    _step(head, dict(bd))                                    # warm-up (allocator, library handles)
+    torch.cuda.synchronize()
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        loss, tb = _step(head, dict(bd))
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    assert torch.isfinite(loss)
