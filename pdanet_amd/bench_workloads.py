@@ -210,7 +210,7 @@ class TrainStepWorkload(BackboneWorkload):
         self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if amp else "")
         self.opt = optimization.build_optimizer(self.model, self.OPTIM)     # flat buffers BEFORE DDP
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.OPTIM)
-        self.ddp = parallel.wrap_ddp(self.model, device) if world > 1 else None
+        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
         self.it = 0
 
     def step(self):
@@ -226,7 +226,47 @@ class TrainStepWorkload(BackboneWorkload):
         return loss
 
 
+class DetectorTrainWorkload(TrainStepWorkload):
+    """The whole training iteration of PDA-SSD on synthetic scenes + ground truth: IASSD detector
+    (backbone + IASSD_Head: target assignment, all configured losses) forward, backward, gradient
+    clipping and the adam_onecycle step -- tools/train_utils/train_utils.py:34-60 with model_func =
+    model_fn_decorator (pcdet/models/__init__.py).  No host synchronisation inside the step."""
+
+    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml", dataset="once"):
+        from . import detector, optimization, parallel, synth
+        BackboneWorkload.__init__(self, batch, n_points, device, rank, 1, amp=amp, cfg=cfg)
+        self.points_np = synth.batch_points(batch, n_points, config_id=(2 if dataset == "once" else 3) + 10 * rank,
+                                            dist="L", dataset=dataset)
+        self.points = torch.from_numpy(self.points_np).to(device)
+        self.gt = torch.from_numpy(synth.gt_boxes(self.points_np, batch, config_id=2 + 10 * rank, dataset=dataset)).to(device)
+        torch.manual_seed(1234)
+        model, self.cfg = detector.build_detector(cfg)
+        self.model = model.to(device).train()
+        self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if amp else "")
+        self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
+        self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
+        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
+        self.it = 0
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        self.sched.step(self.it)
+        self.opt.zero_grad()
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
+            ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt})
+        ret['loss'].backward()
+        self.opt.step()
+        self.it += 1
+        self.tb = tb
+        return ret['loss']
+
+
 def create(name, batch, n_points, device, rank, world):
+    if name == "detector_train":
+        return DetectorTrainWorkload(batch, n_points, device, rank, world)
+    if name == "kitti_detector_train_bf16":
+        return DetectorTrainWorkload(batch, n_points, device, rank, world, amp=True, cfg="kitti_pda_ssd.yaml",
+                                     dataset="kitti")
     if name == "train_step":
         return TrainStepWorkload(batch, n_points, device, rank, world)
     if name == "kitti_train_bf16":

@@ -57,12 +57,14 @@ def max_over_ranks(value, device):
     return float(t.item())
 
 
-def wrap_ddp(model, device=None, bucket_cap_mb=25):
+def wrap_ddp(model, device=None, bucket_cap_mb=25, grads_are_views=False):
     """DDP wrap as the reference does (tools/train.py:153-154).  The whole gradient (25.5 MB)
     fits ~1 default bucket: at this size the xGMI all-reduce is latency-bound
-    and hides under backward."""
+    and hides under backward.  grads_are_views: the parameters' .grad are views of an optimizer's flat
+    buffer (optimization.FlatAdamOneCycle) and must stay so -- DDP then copies the reduced bucket into
+    them instead of re-pointing .grad at its own buckets."""
     if not dist.is_initialized():
         return model
     ids = [device.index] if device is not None and device.type == "cuda" else None
     return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, bucket_cap_mb=bucket_cap_mb,
-                                                     gradient_as_bucket_view=True)
+                                                     gradient_as_bucket_view=not grads_are_views)

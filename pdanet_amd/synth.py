@@ -51,3 +51,28 @@ def batch_points(b, n, config_id=2, dist="L", dataset="once"):
 
 def batch_xyz(b, n, config_id=2, dist="L", dataset="once"):
     return np.stack([scene(n, config_id, s, dist, dataset)[:, :3] for s in range(b)], axis=0).copy()
+
+
+MEAN_SIZES = {  # BOX_CODER_CONFIG.mean_size of the two PDA-SSD yamls (once :77-83, kitti :73-77)
+    "once": np.array([[4.38, 1.87, 1.59], [11.11, 2.88, 3.41], [7.52, 2.5, 2.62], [0.7, 0.66, 1.69], [2.18, 0.79, 1.43]], np.float32),
+    "kitti": np.array([[3.9, 1.6, 1.56], [0.8, 0.6, 1.73], [1.76, 0.6, 1.73]], np.float32),
+}
+
+
+def gt_boxes(points, b, config_id=2, dataset="once", n_boxes=20, pad_to=24):
+    """(b, pad_to, 8) [x, y, z, dx, dy, dz, heading, class] zero-padded like collate_batch
+    (datasets/dataset.py:179-185): `n_boxes` boxes per scene of the yaml's mean sizes (+-10 %), centred on
+    random points of the scene so that they hold points, random heading and class."""
+    n = points.shape[0] // b
+    out = np.zeros((b, pad_to, 8), np.float32)
+    for s in range(b):
+        rng = np.random.default_rng(1000 * config_id + s + 500)
+        pts = points[s * n:(s + 1) * n, 1:4]
+        cls = rng.integers(0, len(MEAN_SIZES[dataset]), n_boxes)
+        size = MEAN_SIZES[dataset][cls] * rng.uniform(0.9, 1.1, (n_boxes, 3))
+        ctr = pts[rng.integers(0, n, n_boxes)].copy()
+        ctr[:, 2] += 0.5 * size[:, 2] - 0.3                      # the chosen point lies near the box floor
+        out[s, :n_boxes, 0:3], out[s, :n_boxes, 3:6] = ctr, size
+        out[s, :n_boxes, 6] = rng.uniform(-np.pi, np.pi, n_boxes)
+        out[s, :n_boxes, 7] = cls + 1
+    return out
