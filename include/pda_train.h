@@ -38,6 +38,24 @@ int pda_adam_onecycle_step(float *p, const float *g, float *m, float *v, int64_t
 int pda_points_in_boxes(const float *boxes, const float *pts, int32_t *box_idx_of_points, int b, int t,
                         int m, pda_stream_t stream);
 
+/* ---- rotated BEV overlap / IoU / NMS (pcdet/ops/iou3d_nms) --------------------------------------
+ * replace boxes_overlap_bev_gpu / boxes_iou_bev_gpu (src/iou3d_nms.cpp:40-63 / :65-87 ->
+ * iou3d_nms_kernel.cu:236-264): boxes_a (num_a,7), boxes_b (num_b,7) [x,y,z,dx,dy,dz,heading] ->
+ * (num_a,num_b) BEV intersection area / IoU. */
+int pda_boxes_overlap_bev(const float *boxes_a, const float *boxes_b, float *ans_overlap, int num_a,
+                          int num_b, pda_stream_t stream);
+int pda_boxes_iou_bev(const float *boxes_a, const float *boxes_b, float *ans_iou, int num_a, int num_b,
+                      pda_stream_t stream);
+/* replaces nms_gpu / nms_normal_gpu (src/iou3d_nms.cpp:90-138 / :141-188 -> kernels :266-369), for a
+ * whole batch and without the reference's device->host mask copy: boxes (B,N,7), each scene already
+ * sorted by descending score; num_valid (B) int32 or NULL = only the first num_valid[s] boxes of a
+ * scene take part; keep (B,N) int64 = kept indices in score order, padded with -1; num_keep (B) int32.
+ * normal != 0: axis-aligned IoU (nms_normal_gpu).  mask_scratch: B * pda_nms_mask_words(N) uint64.
+ * N <= 32768. */
+int64_t pda_nms_mask_words(int n);
+int pda_nms_bev(const float *boxes, const int32_t *num_valid, int64_t *keep, int32_t *num_keep,
+                uint64_t *mask_scratch, int b, int n, float thresh, int normal, pda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -33,4 +33,8 @@ from .binding import (  # noqa: F401
     chamfer_forward,
     chamfer_backward,
     points_in_boxes_gpu,
+    boxes_overlap_bev_gpu,
+    boxes_iou_bev_gpu,
+    nms_gpu,
+    nms_normal_gpu,
 )

@@ -150,3 +150,32 @@ def points_in_boxes_gpu(boxes, pts, box_idx_of_points):
     m = pts.shape[1]
     return _lib().pda_oracle_points_in_boxes(b, t, m, _f(boxes, (b, t, 7)), _f(pts, (b, m, 3)),
                                              _i(box_idx_of_points, (b, m)))
+
+
+def boxes_overlap_bev_gpu(boxes_a, boxes_b, ans):
+    """iou3d_nms.cpp:40-63."""
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    return _lib().pda_oracle_boxes_bev(na, nb, _f(boxes_a, (na, 7)), _f(boxes_b, (nb, 7)), _f(ans, (na, nb)), 0)
+
+
+def boxes_iou_bev_gpu(boxes_a, boxes_b, ans):
+    """iou3d_nms.cpp:65-87."""
+    na, nb = boxes_a.shape[0], boxes_b.shape[0]
+    return _lib().pda_oracle_boxes_bev(na, nb, _f(boxes_a, (na, 7)), _f(boxes_b, (nb, 7)), _f(ans, (na, nb)), 1)
+
+
+def _nms(boxes, keep, thresh, normal):
+    n = boxes.shape[0]
+    assert keep.dtype == np.int64 and keep.flags.c_contiguous and keep.shape[0] >= n
+    return int(_lib().pda_oracle_nms(n, _f(boxes, (n, 7)), keep.ctypes.data_as(ctypes.POINTER(ctypes.c_longlong)),
+                                     ctypes.c_float(thresh), normal))
+
+
+def nms_gpu(boxes, keep, thresh):
+    """iou3d_nms.cpp:90-138: returns num_to_keep."""
+    return _nms(boxes, keep, thresh, 0)
+
+
+def nms_normal_gpu(boxes, keep, thresh):
+    """iou3d_nms.cpp:141-188."""
+    return _nms(boxes, keep, thresh, 1)

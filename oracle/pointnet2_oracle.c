@@ -462,3 +462,139 @@ PDA_EXPORT int pda_oracle_points_in_boxes(int b, int t, int m, const float *boxe
         }
     return 1;
 }
+
+/* ---- rotated BEV overlap / IoU / NMS ---------------------------------------
+ * iou3d_nms_kernel.cu:14-233 (Point, cross, check_rect_cross, check_in_box2d, intersection,
+ * rotate_around_center, point_cmp, box_overlap), :236-242 iou_bev, :312-322 iou_normal, :266-310 /
+ * :325-369 the 64x64 suppression bit masks, iou3d_nms.cpp:90-138 the greedy host scan.
+ * All arithmetic is float as in the CUDA code (float overloads of cos/sin/atan2/fabs there); the
+ * transcendental calls use the correctly rounded float value (computed in double), in the oracle and
+ * in the HIP kernel alike, because cosf/sinf/atan2f differ by an ulp or two between CUDA, glibc and
+ * OCML.  No FMA contraction (the build uses -ffp-contract=off; nvcc's choice of which product to fuse
+ * is not specified by the source): overlaps can differ from a CUDA run in the last bits. */
+typedef struct { float x, y; } pt2;
+static const float IOU_EPS = 1e-8f;
+
+static inline float f_cos(float a) { return (float)cos((double)a); }
+static inline float f_sin(float a) { return (float)sin((double)a); }
+static inline float cross2(pt2 a, pt2 b) { return a.x * b.y - a.y * b.x; }
+static inline float cross3(pt2 p1, pt2 p2, pt2 p0) { return (p1.x - p0.x) * (p2.y - p0.y) - (p2.x - p0.x) * (p1.y - p0.y); }
+static inline float fminf2(float a, float b) { return a < b ? a : b; }
+static inline float fmaxf2(float a, float b) { return a > b ? a : b; }
+
+static inline int check_rect_cross(pt2 p1, pt2 p2, pt2 q1, pt2 q2) {
+    return fminf2(p1.x, p2.x) <= fmaxf2(q1.x, q2.x) && fminf2(q1.x, q2.x) <= fmaxf2(p1.x, p2.x) &&
+           fminf2(p1.y, p2.y) <= fmaxf2(q1.y, q2.y) && fminf2(q1.y, q2.y) <= fmaxf2(p1.y, p2.y);
+}
+
+static inline int check_in_box2d(const float *box, pt2 p) {
+    const float MARGIN = 1e-2f;
+    const float cx = box[0], cy = box[1];
+    const float c = f_cos(-box[6]), s = f_sin(-box[6]);
+    const float rx = (p.x - cx) * c + (p.y - cy) * (-s);
+    const float ry = (p.x - cx) * s + (p.y - cy) * c;
+    return fabsf(rx) < box[3] / 2 + MARGIN && fabsf(ry) < box[4] / 2 + MARGIN;
+}
+
+static inline int seg_intersection(pt2 p1, pt2 p0, pt2 q1, pt2 q0, pt2 *ans) {
+    if (!check_rect_cross(p0, p1, q0, q1)) return 0;
+    const float s1 = cross3(q0, p1, p0), s2 = cross3(p1, q1, p0), s3 = cross3(p0, q1, q0), s4 = cross3(q1, p1, q0);
+    if (!(s1 * s2 > 0 && s3 * s4 > 0)) return 0;
+    const float s5 = cross3(q1, p1, p0);
+    if (fabsf(s5 - s1) > IOU_EPS) {
+        ans->x = (s5 * q0.x - s1 * q1.x) / (s5 - s1);
+        ans->y = (s5 * q0.y - s1 * q1.y) / (s5 - s1);
+    } else {
+        const float a0 = p0.y - p1.y, b0 = p1.x - p0.x, c0 = p0.x * p1.y - p1.x * p0.y;
+        const float a1 = q0.y - q1.y, b1 = q1.x - q0.x, c1 = q0.x * q1.y - q1.x * q0.y;
+        const float D = a0 * b1 - a1 * b0;
+        ans->x = (b0 * c1 - b1 * c0) / D;
+        ans->y = (a1 * c0 - a0 * c1) / D;
+    }
+    return 1;
+}
+
+static inline pt2 rot_center(pt2 ctr, float c, float s, pt2 p) {
+    pt2 r;
+    r.x = (p.x - ctr.x) * c + (p.y - ctr.y) * (-s) + ctr.x;
+    r.y = (p.x - ctr.x) * s + (p.y - ctr.y) * c + ctr.y;
+    return r;
+}
+
+static float box_overlap(const float *a, const float *b) {
+    const float a_dx = a[3] / 2, b_dx = b[3] / 2, a_dy = a[4] / 2, b_dy = b[4] / 2;
+    pt2 ca = {a[0], a[1]}, cb = {b[0], b[1]};
+    pt2 A[5] = {{a[0] - a_dx, a[1] - a_dy}, {a[0] + a_dx, a[1] - a_dy}, {a[0] + a_dx, a[1] + a_dy}, {a[0] - a_dx, a[1] + a_dy}, {0, 0}};
+    pt2 B[5] = {{b[0] - b_dx, b[1] - b_dy}, {b[0] + b_dx, b[1] - b_dy}, {b[0] + b_dx, b[1] + b_dy}, {b[0] - b_dx, b[1] + b_dy}, {0, 0}};
+    const float ac = f_cos(a[6]), as = f_sin(a[6]), bc = f_cos(b[6]), bs = f_sin(b[6]);
+    for (int k = 0; k < 4; ++k) { A[k] = rot_center(ca, ac, as, A[k]); B[k] = rot_center(cb, bc, bs, B[k]); }
+    A[4] = A[0]; B[4] = B[0];
+    pt2 cp[16], center = {0, 0};
+    int cnt = 0;
+    for (int i = 0; i < 4; ++i)
+        for (int j = 0; j < 4; ++j)
+            if (seg_intersection(A[i + 1], A[i], B[j + 1], B[j], &cp[cnt])) {
+                center.x = center.x + cp[cnt].x; center.y = center.y + cp[cnt].y; cnt++;
+            }
+    for (int k = 0; k < 4; ++k) {
+        if (check_in_box2d(a, B[k])) { center.x = center.x + B[k].x; center.y = center.y + B[k].y; cp[cnt++] = B[k]; }
+        if (check_in_box2d(b, A[k])) { center.x = center.x + A[k].x; center.y = center.y + A[k].y; cp[cnt++] = A[k]; }
+    }
+    center.x /= cnt; center.y /= cnt;    /* cnt == 0: 0/0, unused because the loops below do not run */
+    float ang[16];
+    for (int i = 0; i < cnt; ++i) ang[i] = (float)atan2((double)(cp[i].y - center.y), (double)(cp[i].x - center.x));
+    for (int j = 0; j < cnt - 1; ++j)
+        for (int i = 0; i < cnt - j - 1; ++i)
+            if (ang[i] > ang[i + 1]) {
+                pt2 t = cp[i]; cp[i] = cp[i + 1]; cp[i + 1] = t;
+                float ta = ang[i]; ang[i] = ang[i + 1]; ang[i + 1] = ta;
+            }
+    float area = 0;
+    for (int k = 0; k < cnt - 1; ++k) {
+        pt2 u = {cp[k].x - cp[0].x, cp[k].y - cp[0].y}, v = {cp[k + 1].x - cp[0].x, cp[k + 1].y - cp[0].y};
+        area += cross2(u, v);
+    }
+    return (float)((double)fabsf(area) / 2.0);
+}
+
+static inline float iou_bev(const float *a, const float *b) {
+    const float sa = a[3] * a[4], sb = b[3] * b[4], so = box_overlap(a, b);
+    return so / fmaxf2(sa + sb - so, IOU_EPS);
+}
+
+static inline float iou_normal(const float *a, const float *b) {
+    const float left = fmaxf2(a[0] - a[3] / 2, b[0] - b[3] / 2), right = fminf2(a[0] + a[3] / 2, b[0] + b[3] / 2);
+    const float top = fmaxf2(a[1] - a[4] / 2, b[1] - b[4] / 2), bottom = fminf2(a[1] + a[4] / 2, b[1] + b[4] / 2);
+    const float w = fmaxf2(right - left, 0.f), h = fmaxf2(bottom - top, 0.f);
+    const float inter = w * h, sa = a[3] * a[4], sb = b[3] * b[4];
+    return inter / fmaxf2(sa + sb - inter, IOU_EPS);
+}
+
+/* boxes_overlap_bev_gpu / boxes_iou_bev_gpu (iou3d_nms.cpp:40-87): (na,7) x (nb,7) -> (na,nb) */
+PDA_EXPORT int pda_oracle_boxes_bev(int na, int nb, const float *boxes_a, const float *boxes_b, float *out, int iou) {
+#pragma omp parallel for collapse(2) schedule(static)
+    for (int i = 0; i < na; ++i)
+        for (int j = 0; j < nb; ++j)
+            out[(size_t)i * nb + j] = iou ? iou_bev(boxes_a + (size_t)i * 7, boxes_b + (size_t)j * 7)
+                                          : box_overlap(boxes_a + (size_t)i * 7, boxes_b + (size_t)j * 7);
+    return 1;
+}
+
+/* nms_gpu / nms_normal_gpu (iou3d_nms.cpp:90-188): boxes (n,7) already sorted by descending score;
+ * keep[0..ret) = indices kept by the greedy scan (box i suppresses every later j with IoU > thresh). */
+PDA_EXPORT int pda_oracle_nms(int n, const float *boxes, long long *keep, float thresh, int normal) {
+    unsigned char *removed = (unsigned char *)calloc((size_t)(n > 0 ? n : 1), 1);
+    int num = 0;
+    for (int i = 0; i < n; ++i) {
+        if (removed[i]) continue;
+        keep[num++] = i;
+        for (int j = i + 1; j < n; ++j) {
+            if (removed[j]) continue;
+            const float v = normal ? iou_normal(boxes + (size_t)i * 7, boxes + (size_t)j * 7)
+                                   : iou_bev(boxes + (size_t)i * 7, boxes + (size_t)j * 7);
+            if (v > thresh) removed[j] = 1;
+        }
+    }
+    free(removed);
+    return num;
+}

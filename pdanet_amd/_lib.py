@@ -43,6 +43,10 @@ SIGNATURES = {
     # include/pda_train.h
     "pda_grad_norm": [_vp, ctypes.c_int64, _vp, _vp, _vp],
     "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "pda_boxes_overlap_bev": [_vp, _vp, _vp, _i, _i, _vp],
+    "pda_boxes_iou_bev": [_vp, _vp, _vp, _i, _i, _vp],
+    "pda_nms_mask_words": [_i],
+    "pda_nms_bev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
@@ -69,6 +73,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the ABI lost a symbol
         fn.argtypes = argtypes
         fn.restype = _i
+    lib.pda_nms_mask_words.restype = ctypes.c_int64
     lib.pda_abi_version.restype = _i
     lib.pda_last_error.restype = ctypes.c_char_p
     lib.pda_fp_contract_mode.restype = _i

@@ -1,8 +1,9 @@
 """IASSD detector = IASSD_Backbone + IASSD_Head (pcdet/models/detectors/IASSD.py:3-27,
-detector3d_template.py:45-49 module names `backbone_3d` / `point_head`), training path."""
+detector3d_template.py:45-49 module names `backbone_3d` / `point_head`): training forward (loss) and
+inference forward (batched NMS post-processing; recall bookkeeping is eval tooling and not built)."""
 import torch.nn as nn
 
-from . import config
+from . import config, model_nms_utils
 from .backbone import IASSD_Backbone
 from .iassd_head import IASSD_Head
 
@@ -14,6 +15,7 @@ class IASSD(nn.Module):
         self.point_head = IASSD_Head(num_class=num_class, input_channels=self.backbone_3d.num_point_features,
                                      model_cfg=model_cfg["POINT_HEAD"])
         self.module_list = [self.backbone_3d, self.point_head]
+        self.model_cfg, self.num_class = model_cfg, num_class
 
     def forward(self, batch_dict):
         for m in self.module_list:
@@ -21,7 +23,9 @@ class IASSD(nn.Module):
         if self.training:
             loss, tb_dict = self.point_head.get_loss()
             return {'loss': loss}, tb_dict, {}
-        return batch_dict      # post-processing (NMS) is not part of the train step
+        padded = model_nms_utils.post_processing(batch_dict, self.model_cfg["POST_PROCESSING"], self.num_class)
+        batch_dict['final_padded'] = padded            # device tensors, no synchronisation so far
+        return model_nms_utils.to_pred_dicts(padded), {}   # (pred_dicts, recall_dicts): detectors/IASSD.py:20-22
 
 
 def build_detector(cfg_path="once_pda_ssd.yaml"):

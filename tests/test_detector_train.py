@@ -47,3 +47,33 @@ def test_state_dict_keys_follow_the_reference_detector():
     assert head[0] == "point_head.cls_center_layers.0.weight"
     assert "point_head.box_center_layers.6.bias" in head and model.state_dict()["point_head.box_center_layers.6.bias"].shape == (30,)
     assert model.state_dict()["point_head.cls_center_layers.6.weight"].shape == (5, 256)
+
+
+def test_inference_post_processing_matches_per_scene_reference_algorithm(oracle):
+    """Detector in eval mode: padded batched NMS output == the reference's per-scene algorithm
+    (score threshold -> topk -> rotated NMS -> first NMS_POST_MAXSIZE) evaluated with the CPU oracle."""
+    from pdanet_amd import detector, synth
+    torch.manual_seed(3)
+    model, cfg = detector.build_detector("once_pda_ssd.yaml")
+    model = model.cuda().eval()
+    B, N = 2, 4096
+    pts = torch.from_numpy(synth.batch_points(B, N, config_id=2, dist="L")).cuda()
+    with torch.no_grad():
+        bd = {'batch_size': B, 'points': pts}
+        pred_dicts, _ = model(bd)
+    pp = cfg.MODEL.POST_PROCESSING
+    boxes_all = bd['batch_box_preds'].view(B, -1, 7).cpu().numpy()
+    scores_all = torch.sigmoid(bd['batch_cls_preds']).view(B, boxes_all.shape[1], -1).max(-1)
+    assert len(pred_dicts) == B
+    for s in range(B):
+        sc, lab = scores_all[0][s].cpu().numpy(), scores_all[1][s].cpu().numpy() + 1
+        idx = np.nonzero(sc >= pp.SCORE_THRESH)[0]
+        order = idx[np.argsort(-sc[idx], kind="stable")][: pp.NMS_CONFIG.NMS_PRE_MAXSIZE]
+        keep = np.zeros(max(1, len(order)), np.int64)
+        k = oracle.nms_gpu(np.ascontiguousarray(boxes_all[s][order]), keep, pp.NMS_CONFIG.NMS_THRESH) if len(order) else 0
+        sel = order[keep[:k]][: pp.NMS_CONFIG.NMS_POST_MAXSIZE]
+        got = pred_dicts[s]
+        assert got['pred_boxes'].shape[0] == len(sel) > 0
+        np.testing.assert_array_equal(got['pred_boxes'].cpu().numpy(), boxes_all[s][sel])
+        np.testing.assert_array_equal(got['pred_scores'].cpu().numpy(), sc[sel])
+        np.testing.assert_array_equal(got['pred_labels'].cpu().numpy(), lab[sel])
