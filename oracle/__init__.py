@@ -37,4 +37,11 @@ from .binding import (  # noqa: F401
     boxes_iou_bev_gpu,
     nms_gpu,
     nms_normal_gpu,
+    stack_ball_query_wrapper,
+    stack_group_points_wrapper,
+    stack_group_points_grad_wrapper,
+    stack_farthest_point_sampling_wrapper,
+    stack_three_nn_wrapper,
+    stack_three_interpolate_wrapper,
+    stack_three_interpolate_grad_wrapper,
 )

@@ -179,3 +179,44 @@ def nms_gpu(boxes, keep, thresh):
 def nms_normal_gpu(boxes, keep, thresh):
     """iou3d_nms.cpp:141-188."""
     return _nms(boxes, keep, thresh, 1)
+
+
+# ---- pointnet2_stack entry points (pointnet2_stack/src/pointnet2_api.cpp:12-31), same positional order ----
+def stack_ball_query_wrapper(b, m, radius, nsample, new_xyz, new_xyz_batch_cnt, xyz, xyz_batch_cnt, idx):
+    return _lib().pda_oracle_ball_query_stack(b, m, ctypes.c_float(radius), nsample, _f(new_xyz, (m, 3)),
+                                              _i(new_xyz_batch_cnt, (b,)), _f(xyz), _i(xyz_batch_cnt, (b,)),
+                                              _i(idx, (m, nsample)))
+
+
+def stack_group_points_wrapper(b, m, c, nsample, features, features_batch_cnt, idx, idx_batch_cnt, out):
+    return _lib().pda_oracle_group_points_stack(b, m, c, nsample, _f(features), _i(features_batch_cnt, (b,)),
+                                                _i(idx, (m, nsample)), _i(idx_batch_cnt, (b,)), _f(out, (m, c, nsample)))
+
+
+def stack_group_points_grad_wrapper(b, m, c, n, nsample, grad_out, idx, idx_batch_cnt, features_batch_cnt, grad_features):
+    return _lib().pda_oracle_group_points_grad_stack(b, m, c, n, nsample, _f(grad_out, (m, c, nsample)), _i(idx, (m, nsample)),
+                                                     _i(idx_batch_cnt, (b,)), _i(features_batch_cnt, (b,)),
+                                                     _f(grad_features, (n, c)))
+
+
+def stack_farthest_point_sampling_wrapper(xyz, temp, xyz_batch_cnt, idx, num_sampled_points):
+    b = xyz_batch_cnt.shape[0]
+    return _lib().pda_oracle_stack_furthest_point_sampling(b, _f(xyz), _f(temp), _i(xyz_batch_cnt, (b,)), _i(idx),
+                                                           _i(num_sampled_points, (b,)))
+
+
+def stack_three_nn_wrapper(unknown, unknown_batch_cnt, known, known_batch_cnt, dist2, idx):
+    b, n = unknown_batch_cnt.shape[0], unknown.shape[0]
+    _lib().pda_oracle_three_nn_stack(b, n, _f(unknown, (n, 3)), _i(unknown_batch_cnt, (b,)), _f(known),
+                                     _i(known_batch_cnt, (b,)), _f(dist2, (n, 3)), _i(idx, (n, 3)))
+
+
+def stack_three_interpolate_wrapper(features, idx, weight, out):
+    n, c = idx.shape[0], features.shape[1]
+    _lib().pda_oracle_three_interpolate_stack(n, c, _f(features), _i(idx, (n, 3)), _f(weight, (n, 3)), _f(out, (n, c)))
+
+
+def stack_three_interpolate_grad_wrapper(grad_out, idx, weight, grad_features):
+    n, c = grad_out.shape
+    _lib().pda_oracle_three_interpolate_grad_stack(n, c, _f(grad_out, (n, c)), _i(idx, (n, 3)), _f(weight, (n, 3)),
+                                                   _f(grad_features))

@@ -598,3 +598,174 @@ PDA_EXPORT int pda_oracle_nms(int n, const float *boxes, long long *keep, float 
     free(removed);
     return num;
 }
+
+/* ==== pointnet2_stack variants (pcdet/ops/pointnet2/pointnet2_stack/src) ===========
+ * Variable-length scenes described by *_batch_cnt int arrays; point-major (N, C) features. */
+static int stack_scene_of(const int *cnt, int b, int pt_idx, int *start) {
+    /* the kernels' linear scan (ball_query_gpu.cu:27-35): scene of a global index + that scene's start */
+    int bs = 0, acc = cnt[0], s = 0;
+    for (int k = 1; k < b; ++k) {
+        if (pt_idx < acc) break;
+        s = acc;
+        acc += cnt[k];
+        bs = k;
+    }
+    *start = s;
+    return bs;
+}
+
+static int stack_start(const int *cnt, int bs) {
+    int s = 0;
+    for (int k = 0; k < bs; ++k) s += cnt[k];
+    return s;
+}
+
+/* ball_query_gpu.cu:16-66 ball_query_kernel_stack: LOCAL indices; empty ball writes idx[0] = -1 */
+PDA_EXPORT int pda_oracle_ball_query_stack(int b, int m, float radius, int nsample, const float *new_xyz,
+                                           const int *new_xyz_batch_cnt, const float *xyz_all,
+                                           const int *xyz_batch_cnt, int *idx_all) {
+    const float radius2 = radius * radius;
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int pt = 0; pt < m; ++pt) {
+        int dummy;
+        const int bs = stack_scene_of(new_xyz_batch_cnt, b, pt, &dummy);
+        const float *xyz = xyz_all + (size_t)stack_start(xyz_batch_cnt, bs) * 3;
+        const int n = xyz_batch_cnt[bs];
+        int *idx = idx_all + (size_t)pt * nsample;
+        const float nx = new_xyz[pt * 3 + 0], ny = new_xyz[pt * 3 + 1], nz = new_xyz[pt * 3 + 2];
+        int cnt = 0;
+        for (int k = 0; k < n; ++k) {
+            const float d2 = sqdist3(nx, ny, nz, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+            if (d2 < radius2) {
+                if (cnt == 0)
+                    for (int l = 0; l < nsample; ++l) idx[l] = k;
+                idx[cnt] = k;
+                if (++cnt >= nsample) break;
+            }
+        }
+        if (cnt == 0) idx[0] = -1;
+    }
+    return 1;
+}
+
+/* group_points_gpu.cu:71-102 / :15-45: features (N,C), idx (M,ns) local -> out (M,C,ns); grad scatter-adds */
+PDA_EXPORT int pda_oracle_group_points_stack(int b, int m, int c, int nsample, const float *features,
+                                             const int *features_batch_cnt, const int *idx,
+                                             const int *idx_batch_cnt, float *out) {
+    for (int pt = 0; pt < m; ++pt) {
+        int dummy;
+        const int bs = stack_scene_of(idx_batch_cnt, b, pt, &dummy);
+        const float *f = features + (size_t)stack_start(features_batch_cnt, bs) * c;
+        for (int ch = 0; ch < c; ++ch)
+            for (int s = 0; s < nsample; ++s)
+                out[((size_t)pt * c + ch) * nsample + s] = f[(size_t)idx[(size_t)pt * nsample + s] * c + ch];
+    }
+    return 1;
+}
+
+PDA_EXPORT int pda_oracle_group_points_grad_stack(int b, int m, int c, int n, int nsample, const float *grad_out,
+                                                  const int *idx, const int *idx_batch_cnt,
+                                                  const int *features_batch_cnt, float *grad_features) {
+    (void)n;
+    for (int pt = 0; pt < m; ++pt) {
+        int dummy;
+        const int bs = stack_scene_of(idx_batch_cnt, b, pt, &dummy);
+        float *g = grad_features + (size_t)stack_start(features_batch_cnt, bs) * c;
+        for (int ch = 0; ch < c; ++ch)
+            for (int s = 0; s < nsample; ++s)
+                g[(size_t)idx[(size_t)pt * nsample + s] * c + ch] += grad_out[((size_t)pt * c + ch) * nsample + s];
+    }
+    return 1;
+}
+
+/* sampling_gpu.cu:188-318 stack_farthest_point_sampling_kernel: always block size 1024 (:340), per-scene
+ * n / m, GLOBAL indices (old + xyz_batch_start_idx).  (The kernel writes idxs[0] even when m == 0; here, as
+ * in the HIP kernel, a scene with m == 0 writes nothing.) */
+PDA_EXPORT int pda_oracle_stack_furthest_point_sampling(int b, const float *xyz_all, float *temp_all,
+                                                        const int *xyz_batch_cnt, int *idxs_all,
+                                                        const int *num_sampled_points) {
+    const int block_size = 1024;
+#pragma omp parallel for schedule(static)
+    for (int bs = 0; bs < b; ++bs) {
+        const int start = stack_start(xyz_batch_cnt, bs), istart = stack_start(num_sampled_points, bs);
+        const float *dataset = xyz_all + (size_t)start * 3;
+        float *temp = temp_all + start;
+        int *idxs = idxs_all + istart;
+        const int n = xyz_batch_cnt[bs], m = num_sampled_points[bs];
+        if (m <= 0) continue;
+        float *dists = (float *)malloc(sizeof(float) * block_size);
+        int *dists_i = (int *)malloc(sizeof(int) * block_size);
+        int old = 0;
+        idxs[0] = start;
+        for (int j = 1; j < m; ++j) {
+            const float x1 = dataset[old * 3 + 0], y1 = dataset[old * 3 + 1], z1 = dataset[old * 3 + 2];
+            for (int tid = 0; tid < block_size; ++tid) {
+                int besti = 0;
+                float best = -1;
+                for (int k = tid; k < n; k += block_size) {
+                    const float d = sqdist3(dataset[k * 3 + 0], dataset[k * 3 + 1], dataset[k * 3 + 2], x1, y1, z1);
+                    const float d2 = d < temp[k] ? d : temp[k];
+                    temp[k] = d2;
+                    besti = d2 > best ? k : besti;
+                    best = d2 > best ? d2 : best;
+                }
+                dists[tid] = best;
+                dists_i[tid] = besti;
+            }
+            fps_tree_reduce(dists, dists_i, block_size);
+            old = dists_i[0];
+            idxs[j] = old + start;
+        }
+        free(dists);
+        free(dists_i);
+    }
+    return 1;
+}
+
+/* interpolate_gpu.cu:16-75 three_nn_kernel_stack: GLOBAL known indices */
+PDA_EXPORT void pda_oracle_three_nn_stack(int b, int n, const float *unknown, const int *unknown_batch_cnt,
+                                          const float *known_all, const int *known_batch_cnt, float *dist2_all,
+                                          int *idx_all) {
+#pragma omp parallel for schedule(static)
+    for (int pt = 0; pt < n; ++pt) {
+        int dummy;
+        const int bs = stack_scene_of(unknown_batch_cnt, b, pt, &dummy);
+        const int kstart = stack_start(known_batch_cnt, bs), m = known_batch_cnt[bs];
+        const float *known = known_all + (size_t)kstart * 3;
+        const float ux = unknown[pt * 3 + 0], uy = unknown[pt * 3 + 1], uz = unknown[pt * 3 + 2];
+        double best1 = 1e40, best2 = 1e40, best3 = 1e40;
+        int besti1 = 0, besti2 = 0, besti3 = 0;
+        for (int k = 0; k < m; ++k) {
+            const float d = sqdist3(ux, uy, uz, known[k * 3 + 0], known[k * 3 + 1], known[k * 3 + 2]);
+            if (d < best1) { best3 = best2; besti3 = besti2; best2 = best1; besti2 = besti1; best1 = d; besti1 = k; }
+            else if (d < best2) { best3 = best2; besti3 = besti2; best2 = d; besti2 = k; }
+            else if (d < best3) { best3 = d; besti3 = k; }
+        }
+        dist2_all[pt * 3 + 0] = (float)best1; dist2_all[pt * 3 + 1] = (float)best2; dist2_all[pt * 3 + 2] = (float)best3;
+        idx_all[pt * 3 + 0] = besti1 + kstart; idx_all[pt * 3 + 1] = besti2 + kstart; idx_all[pt * 3 + 2] = besti3 + kstart;
+    }
+}
+
+/* interpolate_gpu.cu:107-125 / :151-168: features (M,C), idx/weight (N,3) -> out (N,C); grad scatter-adds */
+PDA_EXPORT void pda_oracle_three_interpolate_stack(int n, int c, const float *features, const int *idx,
+                                                   const float *weight, float *out) {
+    for (int pt = 0; pt < n; ++pt)
+        for (int ch = 0; ch < c; ++ch) {
+            const float p0 = features[(size_t)idx[pt * 3 + 0] * c + ch], p1 = features[(size_t)idx[pt * 3 + 1] * c + ch],
+                        p2 = features[(size_t)idx[pt * 3 + 2] * c + ch];
+            const float w0 = weight[pt * 3 + 0], w1 = weight[pt * 3 + 1], w2 = weight[pt * 3 + 2];
+#if PDA_ORACLE_CONTRACT
+            out[(size_t)pt * c + ch] = fmaf(w2, p2, fmaf(w1, p1, w0 * p0));
+#else
+            out[(size_t)pt * c + ch] = w0 * p0 + w1 * p1 + w2 * p2;
+#endif
+        }
+}
+
+PDA_EXPORT void pda_oracle_three_interpolate_grad_stack(int n, int c, const float *grad_out, const int *idx,
+                                                        const float *weight, float *grad_features) {
+    for (int pt = 0; pt < n; ++pt)
+        for (int ch = 0; ch < c; ++ch)
+            for (int k = 0; k < 3; ++k)
+                grad_features[(size_t)idx[pt * 3 + k] * c + ch] += grad_out[(size_t)pt * c + ch] * weight[pt * 3 + k];
+}

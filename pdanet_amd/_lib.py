@@ -48,6 +48,14 @@ SIGNATURES = {
     "pda_nms_mask_words": [_i],
     "pda_nms_bev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
     "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
+    # include/pda_pointnet2_stack.h
+    "pda_stack_ball_query": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "pda_stack_group_points": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_stack_group_points_grad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_stack_furthest_point_sampling": [_vp, _vp, _vp, _vp, _vp, _i, _vp],
+    "pda_stack_three_nn": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "pda_stack_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "pda_stack_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
 

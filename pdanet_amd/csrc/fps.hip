@@ -513,6 +513,43 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __
     }
 }
 
+// pointnet2_stack: stack_farthest_point_sampling_kernel (pointnet2_stack/src/sampling_gpu.cu:188-318).  Per-scene
+// n / m come from device arrays, the block size is 1024 whatever n (:340, so the tie-break uses L = 10) and
+// the indices written are global (local + scene start).  Streams xyz / temp like fps_stream_kernel.
+__global__ __launch_bounds__(FPS_THREADS) void fps_stack_kernel(const float* __restrict__ xyz_all, float* __restrict__ temp_all,
+                                                                const int32_t* __restrict__ xyz_batch_cnt,
+                                                                int32_t* __restrict__ idx_all,
+                                                                const int32_t* __restrict__ num_sampled) {
+    __shared__ uint2 slots[2][FPS_WAVES];
+    const int t = threadIdx.x, lane = lane_id(), w = wave_id();
+    int start = 0, istart = 0;
+    for (int k = 0; k < (int)blockIdx.x; ++k) { start += xyz_batch_cnt[k]; istart += num_sampled[k]; }
+    const int n = xyz_batch_cnt[blockIdx.x], m = num_sampled[blockIdx.x];
+    if (m <= 0) return;   // the reference stores idxs[0] even then, i.e. into the next scene's slot or past the end
+    const float* __restrict__ data = xyz_all + (size_t)start * 3;
+    float* __restrict__ temp = temp_all + start;
+    int32_t* __restrict__ idx = idx_all + istart;
+    constexpr int L = 10;
+    int old = 0;
+    if (t == 0) idx[0] = start;
+    for (int j = 1; j < m; ++j) {
+        const float x1 = data[old * 3 + 0], y1 = data[old * 3 + 1], z1 = data[old * 3 + 2];
+        float best = -1.f;
+        int bk = 0;
+        for (int k = t; k < n; k += FPS_THREADS) {
+            const float d = sqdist3(data[k * 3 + 0], data[k * 3 + 1], data[k * 3 + 2], x1, y1, z1);
+            const float d2 = fminf(d, temp[k]);
+            temp[k] = d2;
+            const bool g = d2 > best;
+            bk = g ? k : bk;
+            best = g ? d2 : best;
+        }
+        const uint32_t T = best >= 0.f ? fps_tiebreak((uint32_t)bk, L) : 0xffffffffu;
+        old = fps_block_argmax(best, T, slots[j & 1], FPS_WAVES, w, lane, L);
+        if (t == 0) idx[j] = old + start;
+    }
+}
+
 static int ilog2(int v) {
     int l = 0;
     while ((1 << (l + 1)) <= v) ++l;
@@ -601,4 +638,14 @@ PDA_API int pda_furthest_point_sampling_with_dist(const float* dist, float* temp
                                                   int n, int m, pda_stream_t stream) {
     return pda::launch_fps(true, dist, temp, idx, b, n, m, (hipStream_t)stream,
                            "pda_furthest_point_sampling_with_dist");
+}
+
+PDA_API int pda_stack_furthest_point_sampling(const float* xyz, float* temp, const int32_t* xyz_batch_cnt, int32_t* idx,
+                                              const int32_t* num_sampled_points, int b, pda_stream_t stream) {
+    PDA_REQUIRE(b >= 0, "pda_stack_furthest_point_sampling: b=%d", b);
+    if (b == 0) return PDA_OK;
+    PDA_REQUIRE(xyz && temp && xyz_batch_cnt && idx && num_sampled_points, "pda_stack_furthest_point_sampling: null pointer");
+    hipLaunchKernelGGL(pda::fps_stack_kernel, dim3(b), dim3(pda::FPS_THREADS), 0, (hipStream_t)stream, xyz, temp,
+                       xyz_batch_cnt, idx, num_sampled_points);
+    return pda::check_launch("pda_stack_furthest_point_sampling");
 }

@@ -7,6 +7,7 @@
 
 #include "../../include/pda_pointnet2.h"
 #include "../../include/pda_train.h"
+#include "../../include/pda_pointnet2_stack.h"
 
 #ifndef PDA_FP_CONTRACT
 #define PDA_FP_CONTRACT 1  // 1: fma(dz,dz,fma(dy,dy,dx*dx)) (nvcc -fmad=true); 0: uncontracted

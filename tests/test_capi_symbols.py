@@ -17,7 +17,7 @@ def lib():
 
 
 def _declared_symbols():
-    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("pda_pointnet2.h", "pda_train.h"))
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in ("pda_pointnet2.h", "pda_train.h", "pda_pointnet2_stack.h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(pda_[a-z0-9_]+)\s*\(", src)))
 
