@@ -29,6 +29,22 @@ int pda_adam_onecycle_step(float *p, const float *g, float *m, float *v, int64_t
                            float beta1, float beta2, float eps, float wd, int step,
                            const float *total_norm, float max_norm, pda_stream_t stream);
 
+/* ---- training-mode BatchNorm + ReLU over the last dimension (MI355X extension) ---------------------
+ * The point-major form of the reference's Conv1x1 -> BatchNorm -> ReLU stacks (pointnet2_modules.py:
+ * 1605-1611, :628-671): x (rows, C) -> y = relu((x - mean_c) / sqrt(var_c + eps) * gamma_c + beta_c) with
+ * batch statistics over the rows (biased variance), running statistics updated as nn.BatchNorm does
+ * (momentum, unbiased variance; pass NULL for both to skip).  mean_invstd (2, C) is written for the
+ * backward pass.  Backward: grad_x (rows, C), grad_gamma (C), grad_beta (C) are fully written.
+ * C: power of two in [4, 1024]; anything else returns PDA_ERR_INVALID_ARGUMENT (callers keep the
+ * framework's batch_norm + relu).  scratch: pda_bn_relu_scratch_bytes(C) bytes, 16-byte aligned. */
+int64_t pda_bn_relu_scratch_bytes(int c);
+int pda_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float *running_mean,
+                    float *running_var, float *y, float *mean_invstd, void *scratch, int64_t rows, int c,
+                    float eps, float momentum, pda_stream_t stream);
+int pda_bn_relu_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
+                    const float *mean_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
+                    void *scratch, int64_t rows, int c, pda_stream_t stream);
+
 /* ---- target assignment ------------------------------------------------------------------------
  * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
  * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],

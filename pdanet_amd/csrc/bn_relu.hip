@@ -1,0 +1,237 @@
+// bn_relu.hip -- training-mode BatchNorm + ReLU over the LAST dimension of a (rows, C) tensor, forward and
+// backward (include/pda_train.h).  The PDA / SA layers run point-major, so every
+// Conv1x1 -> BatchNorm -> ReLU of the reference (pointnet2_modules.py:1605-1611, :628-671) is
+// linear -> BN -> ReLU over rows = B*npoint*nsample.  Through torch that is MIOpen's spatial BN (3 kernels
+// forward, 3 backward) plus separate ReLU forward/backward passes: 13 trips over the activation per layer.
+// Here: forward = statistics pass + normalise/ReLU pass (2 reads, 1 write); backward = reduction pass +
+// gradient pass (4 reads, 1 write); the ReLU mask is recomputed from x, never stored.
+//
+// Layout: C is a power of two, 4 <= C <= 1024; a thread owns 4 consecutive channels (16-byte accesses) and
+// 256/(C/4) rows per step; per-channel sums are accumulated in double per thread, reduced over the block
+// in LDS and written as per-block partials that a one-block kernel adds in fixed order (deterministic).
+#include "pda_common.h"
+
+namespace pda {
+
+constexpr int BN_BLOCKS = 512;
+
+struct BnShape {
+    int64_t rows;
+    int c, cg, rpb;  // cg = C/4 thread columns; rpb = rows per block step = 256 / cg (>= 1)
+};
+
+__device__ __forceinline__ void block_reduce_cols(double (&a)[4], double (&b)[4], double* lds, int cg, int rpb, double* out_a,
+                                                  double* out_b) {
+    // threads (r, col): reduce over r = tid / cg for every col = tid % cg; results for 4*cg channels
+    const int tid = threadIdx.x;
+    double* la = lds;             // [256][4]
+    double* lb = lds + 256 * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { la[tid * 4 + k] = a[k]; lb[tid * 4 + k] = b[k]; }
+    __syncthreads();
+    if (tid < cg) {
+        double sa[4] = {0, 0, 0, 0}, sb[4] = {0, 0, 0, 0};
+        for (int r = 0; r < rpb; ++r)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { sa[k] += la[(r * cg + tid) * 4 + k]; sb[k] += lb[(r * cg + tid) * 4 + k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { out_a[tid * 4 + k] = sa[k]; out_b[tid * 4 + k] = sb[k]; }
+    }
+}
+
+// BWD == false: partial[blk][0][c] = sum x, [1][c] = sum x^2
+// BWD == true : with dyh = dy * [(x - mean) * invstd * gamma + beta > 0]: [0][c] = sum dyh, [1][c] = sum dyh * xhat
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, double* __restrict__ partial, BnShape s) {
+    __shared__ double lds[2 * 256 * 4];
+    const int tid = threadIdx.x;
+    double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
+    if (s.cg <= 256) {
+        const int col = tid % s.cg, r0 = tid / s.cg;
+        float4 mu = make_float4(0, 0, 0, 0), is = mu, g = mu, be = mu;
+        if (BWD) {
+            mu = reinterpret_cast<const float4*>(mean_invstd)[col];
+            is = reinterpret_cast<const float4*>(mean_invstd + s.c)[col];
+            g = reinterpret_cast<const float4*>(gamma)[col];
+            be = reinterpret_cast<const float4*>(beta)[col];
+        }
+        for (int64_t r = (int64_t)blockIdx.x * s.rpb + r0; r < s.rows; r += (int64_t)gridDim.x * s.rpb) {
+            const float4 v = reinterpret_cast<const float4*>(x + r * s.c)[col];
+            if (!BWD) {
+                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
+                b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
+            } else {
+                const float4 d = reinterpret_cast<const float4*>(dy + r * s.c)[col];
+                const float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
+                const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {be.x, be.y, be.z, be.w}, dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float dyh = (xh[k] * gg[k] + bb[k] > 0.f) ? dd[k] : 0.f;
+                    a[k] += dyh;
+                    b[k] += (double)dyh * xh[k];
+                }
+            }
+        }
+    }
+    double* pa = partial + (size_t)blockIdx.x * 2 * s.c;
+    block_reduce_cols(a, b, lds, s.cg, s.rpb, pa, pa + s.c);
+}
+
+// finalize kernels: grid = ceil(C/64) blocks of 1024 threads = 64 channels x 16 slices of the per-block partials
+// (a single-thread-per-channel loop over 512 partials would serialise ~1000 dependent loads per layer)
+__device__ __forceinline__ bool sum_partials(const double* __restrict__ partial, int nblocks, int c, double& s1, double& s2, int& ch) {
+    __shared__ double red[2][16][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    ch = blockIdx.x * 64 + cl;
+    double a = 0, b = 0;
+    if (ch < c) {
+        // BN_BLOCKS / 16 = 32 loads per sum and thread at most: issue them in independent groups of 8
+        double va[8], vb[8];
+        for (int k0 = part; k0 < nblocks; k0 += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                va[u] = k < nblocks ? partial[(size_t)k * 2 * c + ch] : 0.0;
+                vb[u] = k < nblocks ? partial[(size_t)k * 2 * c + c + ch] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+    }
+    red[0][part][cl] = a; red[1][part][cl] = b;
+    __syncthreads();
+    if (part != 0 || ch >= c) return false;
+    s1 = 0; s2 = 0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { s1 += red[0][p][cl]; s2 += red[1][p][cl]; }
+    return true;
+}
+
+// forward: mean / invstd (biased variance), running statistics (unbiased variance, momentum)
+__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
+                                                               float eps, float momentum, float* __restrict__ mean_invstd,
+                                                               float* __restrict__ running_mean, float* __restrict__ running_var) {
+    double s1, s2;
+    int ch;
+    if (!sum_partials(partial, nblocks, c, s1, s2, ch)) return;
+    const double mean = s1 / (double)rows;
+    double var = s2 / (double)rows - mean * mean;
+    var = var < 0 ? 0 : var;
+    mean_invstd[ch] = (float)mean;
+    mean_invstd[c + ch] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        const double unbiased = rows > 1 ? var * ((double)rows / (double)(rows - 1)) : var;
+        running_mean[ch] = (float)((1.0 - momentum) * running_mean[ch] + momentum * mean);
+        running_var[ch] = (float)((1.0 - momentum) * running_var[ch] + momentum * unbiased);
+    }
+}
+
+// backward: dgamma = sum dyh*xhat, dbeta = sum dyh; sums[0][c] = dbeta / rows, sums[1][c] = dgamma / rows
+__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ sums) {
+    double s1, s2;
+    int ch;
+    if (!sum_partials(partial, nblocks, c, s1, s2, ch)) return;
+    dbeta[ch] = (float)s1;
+    dgamma[ch] = (float)s2;
+    sums[ch] = (float)(s1 / (double)rows);
+    sums[c + ch] = (float)(s2 / (double)rows);
+}
+
+// BWD == false: y = relu((x - mean) * invstd * gamma + beta)
+// BWD == true : dx = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat))
+template <bool BWD>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ sums,
+                                                       float* __restrict__ out, BnShape s) {
+    const int tid = threadIdx.x;
+    const int col = tid % s.cg, r0 = tid / s.cg;
+    const float4 mu = reinterpret_cast<const float4*>(mean_invstd)[col], is = reinterpret_cast<const float4*>(mean_invstd + s.c)[col];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+    float4 m1 = make_float4(0, 0, 0, 0), m2 = m1;
+    if (BWD) { m1 = reinterpret_cast<const float4*>(sums)[col]; m2 = reinterpret_cast<const float4*>(sums + s.c)[col]; }
+    const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w}, gv[4] = {g.x, g.y, g.z, g.w},
+                bv[4] = {be.x, be.y, be.z, be.w}, m1v[4] = {m1.x, m1.y, m1.z, m1.w}, m2v[4] = {m2.x, m2.y, m2.z, m2.w};
+    for (int64_t r = (int64_t)blockIdx.x * s.rpb + r0; r < s.rows; r += (int64_t)gridDim.x * s.rpb) {
+        const float4 v = reinterpret_cast<const float4*>(x + r * s.c)[col];
+        const float xv[4] = {v.x, v.y, v.z, v.w};
+        float o[4];
+        if (!BWD) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = fmaxf((xv[k] - muv[k]) * isv[k] * gv[k] + bv[k], 0.f);
+        } else {
+            const float4 d = reinterpret_cast<const float4*>(dy + r * s.c)[col];
+            const float dv[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xh = (xv[k] - muv[k]) * isv[k];
+                const float dyh = (xh * gv[k] + bv[k] > 0.f) ? dv[k] : 0.f;
+                o[k] = gv[k] * isv[k] * (dyh - m1v[k] - xh * m2v[k]);
+            }
+        }
+        reinterpret_cast<float4*>(out + r * s.c)[col] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int bn_shape(int64_t rows, int c, BnShape& s, const char* what) {
+    PDA_REQUIRE(rows >= 1, "%s: rows = %lld", what, (long long)rows);
+    PDA_REQUIRE(c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "%s: C = %d is not a power of two in [4, 1024]", what, c);
+    s.rows = rows; s.c = c; s.cg = c / 4; s.rpb = 256 / s.cg;
+    return PDA_OK;
+}
+
+static int bn_grid(const BnShape& s) {
+    const int64_t steps = divup64(s.rows, s.rpb);
+    return (int)(steps < BN_BLOCKS ? steps : BN_BLOCKS);
+}
+
+}  // namespace pda
+
+PDA_API int64_t pda_bn_relu_scratch_bytes(int c) {
+    const int64_t cc = c > 0 ? c : 0;
+    return (int64_t)pda::BN_BLOCKS * 2 * cc * (int64_t)sizeof(double) + 2 * cc * (int64_t)sizeof(float);
+}
+
+PDA_API int pda_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                            float* y, float* mean_invstd, void* scratch, int64_t rows, int c, float eps, float momentum,
+                            pda_stream_t stream) {
+    pda::BnShape s;
+    if (int st = pda::bn_shape(rows, c, s, "pda_bn_relu_fwd")) return st;
+    PDA_REQUIRE(x && gamma && beta && y && mean_invstd && scratch, "pda_bn_relu_fwd: null pointer");
+    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "pda_bn_relu_fwd: running_mean/var must come together");
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
+                "pda_bn_relu_fwd: pointers must be 16-byte aligned");
+    const int grid = pda::bn_grid(s);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pda::bn_reduce_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
+    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 64)), dim3(1024), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
+                       mean_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(pda::bn_apply_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, mean_invstd, gamma, beta,
+                       (const float*)nullptr, y, s);
+    return pda::check_launch("pda_bn_relu_fwd");
+}
+
+PDA_API int pda_bn_relu_bwd(const float* x, const float* grad_y, const float* gamma, const float* beta, const float* mean_invstd,
+                            float* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c,
+                            pda_stream_t stream) {
+    pda::BnShape s;
+    if (int st = pda::bn_shape(rows, c, s, "pda_bn_relu_bwd")) return st;
+    PDA_REQUIRE(x && grad_y && gamma && beta && mean_invstd && grad_x && grad_gamma && grad_beta && scratch,
+                "pda_bn_relu_bwd: null pointer");
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
+                "pda_bn_relu_bwd: pointers must be 16-byte aligned");
+    const int grid = pda::bn_grid(s);
+    hipStream_t st = (hipStream_t)stream;
+    // the per-channel means of the second pass live behind the partials in the scratch buffer
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)pda::BN_BLOCKS * 2 * c);
+    hipLaunchKernelGGL(pda::bn_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, (double*)scratch, s);
+    hipLaunchKernelGGL(pda::bn_finalize_bwd_kernel, dim3(pda::divup(c, 64)), dim3(1024), 0, st, (const double*)scratch, grid, c, rows, grad_gamma,
+                       grad_beta, sums);
+    hipLaunchKernelGGL(pda::bn_apply_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, sums, grad_x, s);
+    return pda::check_launch("pda_bn_relu_bwd");
+}

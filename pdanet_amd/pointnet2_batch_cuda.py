@@ -200,3 +200,26 @@ def group_attention_bwd(qkv, grad_out, lse, grad_qkv, num_groups, seq, heads, he
     _call("pda_group_attention_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32),
           _chk(lse, "lse", F32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
     return 1
+
+
+def bn_relu_scratch_bytes(c):
+    return int(_lib.load().pda_bn_relu_scratch_bytes(int(c)))
+
+
+def bn_relu_fwd(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum):
+    """MI355X extension: training-mode BatchNorm + ReLU over the last dim (csrc/bn_relu.hip)."""
+    _numel_ok(x, rows * c, "x"); _numel_ok(y, rows * c, "y"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
+    rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
+    rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _call("pda_bn_relu_fwd", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv,
+          _chk(y, "y", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c,
+          float(eps), float(momentum))
+    return 1
+
+
+def bn_relu_bwd(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c):
+    _numel_ok(x, rows * c, "x"); _numel_ok(grad_y, rows * c, "grad_y"); _numel_ok(grad_x, rows * c, "grad_x")
+    _call("pda_bn_relu_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32),
+          _chk(beta, "beta", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", F32),
+          _chk(grad_gamma, "grad_gamma", F32), _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c)
+    return 1

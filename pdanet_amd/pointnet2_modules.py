@@ -81,13 +81,32 @@ def _bn_lastdim(bn, x):
     return y.permute(0, 2, 3, 1).reshape(shp)
 
 
+FUSED_BN_RELU = True   # csrc/bn_relu.hip instead of F.batch_norm + F.relu in training mode
+
+
+def _bn_relu_lastdim(bn, x):
+    """relu(bn(x)) over the last dim: one fused kernel pair in training mode, else torch."""
+    if FUSED_BN_RELU and pointnet2_utils.BatchNormReLU.supported(x, bn):
+        return pointnet2_utils.batch_norm_relu(bn, x)
+    return F.relu(_bn_lastdim(bn, x))
+
+
 def _mlp_lastdim(layers, x):
     """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x."""
-    for m in layers:
+    layers = list(layers)
+    skip = False
+    for k, m in enumerate(layers):
+        if skip:
+            skip = False
+            continue
         if isinstance(m, (nn.Conv2d, nn.Conv1d)):
             x = F.linear(x, m.weight.flatten(1), m.bias)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
-            x = _bn_lastdim(m, x)
+            if k + 1 < len(layers) and isinstance(layers[k + 1], nn.ReLU):
+                x = _bn_relu_lastdim(m, x)
+                skip = True
+            else:
+                x = _bn_lastdim(m, x)
         elif isinstance(m, nn.ReLU):
             x = F.relu(x)
         else:
@@ -517,7 +536,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             dscale = density / density.max(dim=2, keepdim=True)[0]
             dn = self.point_density[i].densitynet
             for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
-                dscale = F.relu(_bn_lastdim(bn, F.linear(dscale, conv.weight.flatten(1), conv.bias)))
+                dscale = _bn_relu_lastdim(bn, F.linear(dscale, conv.weight.flatten(1), conv.bias))
             # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
             rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)

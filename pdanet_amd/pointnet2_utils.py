@@ -247,6 +247,49 @@ class GroupAttention(Function):
 group_attention = GroupAttention.apply
 
 
+class BatchNormReLU(Function):
+    """MI355X extension: training-mode BatchNorm over the last dim of x (..., C) followed by ReLU, forward
+    and backward in csrc/bn_relu.hip (statistics over all leading dims, like BatchNorm2d over (B, C, H, W)
+    of the channel-major tensor; running statistics updated in place)."""
+
+    @staticmethod
+    def supported(x, bn):
+        c = x.shape[-1]
+        return (x.is_cuda and x.dtype == torch.float32 and bn.training and bn.affine and bn.momentum is not None
+                and 4 <= c <= 1024 and (c & (c - 1)) == 0 and x.numel() > 0)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        x = x.contiguous()
+        c = x.shape[-1]
+        rows = x.numel() // c
+        y = torch.empty_like(x)
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_fwd(x, weight, bias, running_mean, running_var, y, stats, scratch, rows, c, eps, momentum)
+        ctx.save_for_backward(x, weight, bias, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, bias, stats = ctx.saved_tensors
+        c = x.shape[-1]
+        rows = x.numel() // c
+        grad_x = torch.empty_like(x)
+        gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_bwd(x, grad_y.contiguous(), weight, bias, stats, grad_x, gw, gb, scratch, rows, c)
+        return grad_x, gw, gb, None, None, None, None
+
+
+def batch_norm_relu(bn, x):
+    """relu(bn(x)) for an nn.BatchNorm{1,2}d module over the LAST dim of x (training mode, fp32)."""
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
+
+
 class BallQuery(Function):
     """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
 

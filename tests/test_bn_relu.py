@@ -1,0 +1,62 @@
+"""csrc/bn_relu.hip against torch (float64 reference): training-mode BatchNorm + ReLU over the last dim.
+Floating point: outputs within 2e-5, gradients within 2e-5 of the largest gradient, running statistics 1e-6."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 7, 4), (3, 50, 16, 8), (2, 1000, 32, 16), (1, 4099, 64), (2, 300, 8, 512), (5, 1024), (2, 128, 16, 256)])
+def test_forward_backward_running_stats(shape):
+    from pdanet_amd import pointnet2_utils as pu
+    torch.manual_seed(sum(shape))
+    c = shape[-1]
+    bn = nn.BatchNorm1d(c).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.3)
+        bn.running_mean.normal_(); bn.running_var.uniform_(0.5, 2)
+    ref = nn.BatchNorm1d(c).cuda().double().train()
+    ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    x = (torch.randn(shape, device="cuda") * 1.7 + 0.4).requires_grad_(True)
+    assert pu.BatchNormReLU.supported(x, bn)
+    y = pu.batch_norm_relu(bn, x)
+    xr = x.detach().double().requires_grad_(True)
+    yr = F.relu(ref(xr.reshape(-1, c))).reshape(shape)
+    assert (y.double() - yr).abs().max().item() < 2e-5
+    go = torch.randn_like(y)
+    gx, gw, gb = torch.autograd.grad(y, [x, bn.weight, bn.bias], go)
+    rx, rw, rb = torch.autograd.grad(yr, [xr, ref.weight, ref.bias], go.double())
+    for a, b in ((gx, rx), (gw, rw), (gb, rb)):
+        assert (a.double() - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+    assert torch.allclose(bn.running_mean.double(), ref.running_mean, atol=1e-6)
+    assert torch.allclose(bn.running_var.double(), ref.running_var, atol=1e-6, rtol=1e-6)
+    assert int(bn.num_batches_tracked) == 1
+
+
+def test_unsupported_cases_use_torch():
+    from pdanet_amd import pointnet2_modules as pm, pointnet2_utils as pu
+    bn = nn.BatchNorm1d(96).cuda().train()
+    x = torch.randn(4, 10, 96, device="cuda")
+    assert not pu.BatchNormReLU.supported(x, bn)                      # not a power of two
+    assert not pu.BatchNormReLU.supported(torch.randn(4, 10, 64, device="cuda"), nn.BatchNorm1d(64).cuda().eval())
+    y = pm._bn_relu_lastdim(bn, x)
+    assert y.shape == x.shape and float(y.min()) >= 0
+
+
+def test_mlp_helper_fused_equals_unfused():
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(0)
+    mlp = nn.Sequential(nn.Conv2d(12, 32, 1, bias=False), nn.BatchNorm2d(32), nn.ReLU(),
+                        nn.Conv2d(32, 64, 1, bias=False), nn.BatchNorm2d(64), nn.ReLU()).cuda().train()
+    x = torch.randn(2, 500, 16, 12, device="cuda", requires_grad=True)
+    outs = []
+    for flag in (True, False):
+        pm.FUSED_BN_RELU = flag
+        y = pm._mlp_lastdim(mlp, x)
+        (g,) = torch.autograd.grad(y.square().mean(), x)
+        outs.append((y.detach(), g))
+    pm.FUSED_BN_RELU = True
+    assert torch.allclose(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-5)
+    assert torch.allclose(outs[0][1], outs[1][1], atol=1e-8 + 2e-5 * outs[1][1].abs().max().item())
