@@ -45,6 +45,20 @@ int pda_bn_relu_bwd(const float *x, const float *grad_y, const float *gamma, con
                     const float *mean_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
                     void *scratch, int64_t rows, int c, pda_stream_t stream);
 
+/* ---- LayerNorm over the last dimension with optional fused residual add (MI355X extension) ----------
+ * nn.LayerNorm(D) of TransformerEncoderLayerPreNorm (PointFormer.py:17-18,29,33): x (rows, D) [+ residual
+ * (rows, D), the sum also written to sum_out] -> y = (s - mean) / sqrt(var + eps) * gamma + beta per row
+ * (biased variance); mean_rstd (rows, 2) kept for the backward pass, whose x argument is the normalised
+ * tensor (x, or sum_out when a residual was added).  grad_x / grad_gamma / grad_beta are fully written.
+ * D in {256, 512, 1024}.  scratch: pda_layer_norm_scratch_bytes(D) bytes. */
+int64_t pda_layer_norm_scratch_bytes(int d);
+int pda_layer_norm_fwd(const float *x, const float *residual, const float *gamma, const float *beta,
+                       float *sum_out, float *y, float *mean_rstd, int64_t rows, int d, float eps,
+                       pda_stream_t stream);
+int pda_layer_norm_bwd(const float *x, const float *grad_y, const float *gamma, const float *mean_rstd,
+                       float *grad_x, float *grad_gamma, float *grad_beta, void *scratch, int64_t rows,
+                       int d, pda_stream_t stream);
+
 /* ---- target assignment ------------------------------------------------------------------------
  * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
  * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],

@@ -1,0 +1,194 @@
+// layer_norm.hip -- LayerNorm over the last dimension with an optional fused residual add, forward and
+// backward (include/pda_train.h).  The PDA layer's TransformerEncoderLayerPreNorm (PointFormer.py:28-38)
+// normalises the (tokens, D) activations twice per scale; D = 256 / 512, tokens = 131k-262k.  Through torch
+// that is a forward kernel plus TWO backward kernels that each re-read x and dy (cuComputeGradInput,
+// cuComputePartGradGammaBeta).  Here: one wave per row, the row lives in registers (D/64 floats per lane,
+// 16-byte accesses), mean / variance by DPP-free butterfly shuffles; backward is ONE pass: dx is written and
+// every lane keeps running sums of dy and dy*xhat for its own columns, reduced over the block in LDS and
+// written as per-block partials that a small second kernel adds in fixed order (deterministic).
+#include "pda_common.h"
+
+namespace pda {
+
+constexpr int LN_BLOCKS = 1024;
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// V = float4 chunks per lane: D = 256 * V
+template <int V, bool RESIDUAL>
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ sum_out, float* __restrict__ y,
+                                                             float* __restrict__ mean_rstd, int64_t rows, float eps) {
+    constexpr int D = 256 * V;
+    const int lane = lane_id();
+    float4 g[V], be[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        g[v] = reinterpret_cast<const float4*>(gamma)[v * 64 + lane];
+        be[v] = reinterpret_cast<const float4*>(beta)[v * 64 + lane];
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + wave_id(); r < rows; r += (int64_t)gridDim.x * 4) {
+        float4 a[V];
+        float s = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            a[v] = reinterpret_cast<const float4*>(x + r * D)[v * 64 + lane];
+            if (RESIDUAL) {
+                const float4 b = reinterpret_cast<const float4*>(res + r * D)[v * 64 + lane];
+                a[v].x += b.x; a[v].y += b.y; a[v].z += b.z; a[v].w += b.w;
+                reinterpret_cast<float4*>(sum_out + r * D)[v * 64 + lane] = a[v];
+            }
+            s += (a[v].x + a[v].y) + (a[v].z + a[v].w);
+        }
+        const float mean = wave_sum(s) * (1.0f / D);
+        float q = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float dx = a[v].x - mean, dy = a[v].y - mean, dz = a[v].z - mean, dw = a[v].w - mean;
+            q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+        }
+        const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / D) + eps);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float4 o;
+            o.x = (a[v].x - mean) * rstd * g[v].x + be[v].x;
+            o.y = (a[v].y - mean) * rstd * g[v].y + be[v].y;
+            o.z = (a[v].z - mean) * rstd * g[v].z + be[v].z;
+            o.w = (a[v].w - mean) * rstd * g[v].w + be[v].w;
+            reinterpret_cast<float4*>(y + r * D)[v * 64 + lane] = o;
+        }
+        if (lane == 0) { mean_rstd[r * 2] = mean; mean_rstd[r * 2 + 1] = rstd; }
+    }
+}
+
+template <int V>
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
+                                                             float* __restrict__ dx, float* __restrict__ partial, int64_t rows) {
+    constexpr int D = 256 * V;
+    __shared__ float red[2][4][D];
+    const int lane = lane_id(), w = wave_id();
+    float4 g[V], sb[V], sg[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        g[v] = reinterpret_cast<const float4*>(gamma)[v * 64 + lane];
+        sb[v] = make_float4(0, 0, 0, 0); sg[v] = make_float4(0, 0, 0, 0);
+    }
+    for (int64_t r = (int64_t)blockIdx.x * 4 + w; r < rows; r += (int64_t)gridDim.x * 4) {
+        const float mean = mean_rstd[r * 2], rstd = mean_rstd[r * 2 + 1];
+        float4 xh[V], d[V];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            const float4 xv = reinterpret_cast<const float4*>(x + r * D)[v * 64 + lane];
+            d[v] = reinterpret_cast<const float4*>(dy + r * D)[v * 64 + lane];
+            xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            sb[v].x += d[v].x; sb[v].y += d[v].y; sb[v].z += d[v].z; sb[v].w += d[v].w;
+            sg[v].x += d[v].x * xh[v].x; sg[v].y += d[v].y * xh[v].y; sg[v].z += d[v].z * xh[v].z; sg[v].w += d[v].w * xh[v].w;
+            d[v].x *= g[v].x; d[v].y *= g[v].y; d[v].z *= g[v].z; d[v].w *= g[v].w;        // dy * gamma
+            s1 += (d[v].x + d[v].y) + (d[v].z + d[v].w);
+            s2 += (d[v].x * xh[v].x + d[v].y * xh[v].y) + (d[v].z * xh[v].z + d[v].w * xh[v].w);
+        }
+        const float m1 = wave_sum(s1) * (1.0f / D), m2 = wave_sum(s2) * (1.0f / D);
+#pragma unroll
+        for (int v = 0; v < V; ++v) {
+            float4 o;
+            o.x = rstd * (d[v].x - m1 - xh[v].x * m2);
+            o.y = rstd * (d[v].y - m1 - xh[v].y * m2);
+            o.z = rstd * (d[v].z - m1 - xh[v].z * m2);
+            o.w = rstd * (d[v].w - m1 - xh[v].w * m2);
+            reinterpret_cast<float4*>(dx + r * D)[v * 64 + lane] = o;
+        }
+    }
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        reinterpret_cast<float4*>(red[0][w])[v * 64 + lane] = sb[v];
+        reinterpret_cast<float4*>(red[1][w])[v * 64 + lane] = sg[v];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < D; c += 256) {
+        partial[((size_t)blockIdx.x * 2 + 0) * D + c] = (red[0][0][c] + red[0][1][c]) + (red[0][2][c] + red[0][3][c]);
+        partial[((size_t)blockIdx.x * 2 + 1) * D + c] = (red[1][0][c] + red[1][1][c]) + (red[1][2][c] + red[1][3][c]);
+    }
+}
+
+// dbeta / dgamma = sum of the per-block partials; 64 columns x 16 slices per block of 1024 threads
+__global__ __launch_bounds__(1024) void layer_norm_finalize_kernel(const float* __restrict__ partial, int nblocks, int d,
+                                                                   float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ float red[2][16][64];
+    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float a = 0.f, b = 0.f;
+    if (c < d) {
+        float va[8], vb[8];
+        for (int k0 = part; k0 < nblocks; k0 += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                va[u] = k < nblocks ? partial[((size_t)k * 2 + 0) * d + c] : 0.f;
+                vb[u] = k < nblocks ? partial[((size_t)k * 2 + 1) * d + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+        }
+    }
+    red[0][part][cl] = a; red[1][part][cl] = b;
+    __syncthreads();
+    if (part != 0 || c >= d) return;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) { s1 += red[0][p][cl]; s2 += red[1][p][cl]; }
+    dbeta[c] = s1;
+    dgamma[c] = s2;
+}
+
+static int ln_grid(int64_t rows) {
+    const int64_t b = divup64(rows, 4);
+    return (int)(b < LN_BLOCKS ? b : LN_BLOCKS);
+}
+
+}  // namespace pda
+
+PDA_API int64_t pda_layer_norm_scratch_bytes(int d) { return (int64_t)pda::LN_BLOCKS * 2 * (d > 0 ? d : 0) * (int64_t)sizeof(float); }
+
+PDA_API int pda_layer_norm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* sum_out,
+                               float* y, float* mean_rstd, int64_t rows, int d, float eps, pda_stream_t stream) {
+    PDA_REQUIRE(rows >= 0, "pda_layer_norm_fwd: rows = %lld", (long long)rows);
+    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "pda_layer_norm_fwd: D = %d (256, 512 or 1024)", d);
+    if (rows == 0) return PDA_OK;
+    PDA_REQUIRE(x && gamma && beta && y && mean_rstd, "pda_layer_norm_fwd: null pointer");
+    PDA_REQUIRE((residual == nullptr) == (sum_out == nullptr), "pda_layer_norm_fwd: residual and sum_out come together");
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual | (uintptr_t)sum_out) & 15) == 0,
+                "pda_layer_norm_fwd: pointers must be 16-byte aligned");
+    const dim3 grid(pda::ln_grid(rows)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define PDA_LN_FWD(V)                                                                                                          \
+    if (residual) hipLaunchKernelGGL((pda::layer_norm_fwd_kernel<V, true>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, mean_rstd, rows, eps); \
+    else hipLaunchKernelGGL((pda::layer_norm_fwd_kernel<V, false>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, mean_rstd, rows, eps)
+    if (d == 256) { PDA_LN_FWD(1); } else if (d == 512) { PDA_LN_FWD(2); } else { PDA_LN_FWD(4); }
+#undef PDA_LN_FWD
+    return pda::check_launch("pda_layer_norm_fwd");
+}
+
+PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, float* grad_x,
+                               float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int d, pda_stream_t stream) {
+    PDA_REQUIRE(rows >= 1, "pda_layer_norm_bwd: rows = %lld", (long long)rows);
+    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "pda_layer_norm_bwd: D = %d (256, 512 or 1024)", d);
+    PDA_REQUIRE(x && grad_y && gamma && mean_rstd && grad_x && grad_gamma && grad_beta && scratch, "pda_layer_norm_bwd: null pointer");
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)gamma) & 15) == 0,
+                "pda_layer_norm_bwd: pointers must be 16-byte aligned");
+    const int nblocks = pda::ln_grid(rows);
+    const dim3 grid(nblocks), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)scratch;
+    if (d == 256) hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<1>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
+    else if (d == 512) hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<2>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
+    else hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<4>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
+    hipLaunchKernelGGL(pda::layer_norm_finalize_kernel, dim3(pda::divup(d, 64)), dim3(1024), 0, st, partial, nblocks, d, grad_gamma, grad_beta);
+    return pda::check_launch("pda_layer_norm_bwd");
+}

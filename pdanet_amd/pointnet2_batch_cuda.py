@@ -223,3 +223,25 @@ def bn_relu_bwd(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_be
           _chk(beta, "beta", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", F32),
           _chk(grad_gamma, "grad_gamma", F32), _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c)
     return 1
+
+
+def layer_norm_scratch_bytes(d):
+    return int(_lib.load().pda_layer_norm_scratch_bytes(int(d)))
+
+
+def layer_norm_fwd(x, residual, gamma, beta, sum_out, y, mean_rstd, rows, d, eps):
+    """MI355X extension: LayerNorm over the last dim with optional fused residual add (csrc/layer_norm.hip)."""
+    _numel_ok(x, rows * d, "x"); _numel_ok(y, rows * d, "y"); _numel_ok(mean_rstd, rows * 2, "mean_rstd")
+    res = None if residual is None else _chk(residual, "residual", F32)
+    so = None if sum_out is None else _chk(sum_out, "sum_out", F32)
+    _call("pda_layer_norm_fwd", x, _chk(x, "x", F32), res, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), so,
+          _chk(y, "y", F32), _chk(mean_rstd, "mean_rstd", F32), rows, d, float(eps))
+    return 1
+
+
+def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, scratch, rows, d):
+    _numel_ok(x, rows * d, "x"); _numel_ok(grad_y, rows * d, "grad_y"); _numel_ok(grad_x, rows * d, "grad_x")
+    _call("pda_layer_norm_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32),
+          _chk(mean_rstd, "mean_rstd", F32), _chk(grad_x, "grad_x", F32), _chk(grad_gamma, "grad_gamma", F32),
+          _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, d)
+    return 1

@@ -82,6 +82,7 @@ def _bn_lastdim(bn, x):
 
 
 FUSED_BN_RELU = True   # csrc/bn_relu.hip instead of F.batch_norm + F.relu in training mode
+FUSED_LAYER_NORM = True   # csrc/layer_norm.hip (with the residual add fused in) instead of F.layer_norm
 
 
 def _bn_relu_lastdim(bn, x):
@@ -120,7 +121,11 @@ def _transformer_batch_first(tr, x):
     attn = tr.self_attn
     assert attn.dropout == 0.0 or not tr.training
     D, H = attn.embed_dim, attn.num_heads
-    src = F.layer_norm(x, (D,), tr.norm1.weight, tr.norm1.bias, tr.norm1.eps)
+    fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D)
+    if fused_ln:
+        src = pointnet2_utils.layer_norm(x, tr.norm1)
+    else:
+        src = F.layer_norm(x, (D,), tr.norm1.weight, tr.norm1.bias, tr.norm1.eps)
     qkv = F.linear(src, attn.in_proj_weight, attn.in_proj_bias)
     Bn, S, _ = qkv.shape
     if GROUP_ATTENTION_KERNEL and pointnet2_utils.GroupAttention.supported(qkv, H):
@@ -128,8 +133,11 @@ def _transformer_batch_first(tr, x):
     else:
         q, k, v = qkv.view(Bn, S, 3, H, D // H).permute(2, 0, 3, 1, 4)  # each (Bn, H, S, hd)
         a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Bn, S, D)
-    src = src + F.linear(a, attn.out_proj.weight, attn.out_proj.bias)
-    src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
+    if fused_ln:   # LayerNorm(src + out_proj(a)) in one kernel
+        src = pointnet2_utils.layer_norm(F.linear(a, attn.out_proj.weight, attn.out_proj.bias), tr.norm2, residual=src)
+    else:
+        src = src + F.linear(a, attn.out_proj.weight, attn.out_proj.bias)
+        src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
     src2 = F.linear(F.relu(F.linear(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)
     return src + src2
 

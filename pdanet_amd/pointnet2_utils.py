@@ -290,6 +290,48 @@ def batch_norm_relu(bn, x):
     return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
 
 
+class LayerNormResidual(Function):
+    """MI355X extension: y = LayerNorm(x [+ residual]) over the last dim (csrc/layer_norm.hip); one forward
+    kernel, one single-pass backward kernel (+ a tiny fixed-order reduction of the gamma/beta partials)."""
+
+    @staticmethod
+    def supported(x, d):
+        return x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == d and d in (256, 512, 1024) and x.numel() > 0
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, eps):
+        x = x.contiguous()
+        d = x.shape[-1]
+        rows = x.numel() // d
+        y = torch.empty_like(x)
+        stats = torch.empty((rows, 2), dtype=torch.float32, device=x.device)
+        if residual is not None:
+            s = torch.empty_like(x)
+            pointnet2.layer_norm_fwd(x, residual.contiguous(), weight, bias, s, y, stats, rows, d, eps)
+        else:
+            s = x
+            pointnet2.layer_norm_fwd(x, None, weight, bias, None, y, stats, rows, d, eps)
+        ctx.save_for_backward(s, weight, stats)
+        ctx.has_residual = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        s, weight, stats = ctx.saved_tensors
+        d = s.shape[-1]
+        rows = s.numel() // d
+        gx = torch.empty_like(s)
+        gw, gb = torch.empty_like(weight), torch.empty_like(weight)
+        scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(d),), dtype=torch.uint8, device=s.device)
+        pointnet2.layer_norm_bwd(s, grad_y.contiguous(), weight, stats, gx, gw, gb, scratch, rows, d)
+        return gx, (gx if ctx.has_residual else None), gw, gb, None
+
+
+def layer_norm(x, ln, residual=None):
+    """nn.LayerNorm module `ln` applied to x (+ residual) over the last dim."""
+    return LayerNormResidual.apply(x, residual, ln.weight, ln.bias, ln.eps)
+
+
 class BallQuery(Function):
     """pointnet2_utils.py:228-253.  idx (B,npoint,nsample) int32, zero-initialised."""
 

@@ -1,0 +1,50 @@
+"""csrc/layer_norm.hip against torch (float64): LayerNorm over the last dim with optional fused residual.
+Outputs within 2e-5, gradients within 2e-5 of the largest gradient."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("rows,d", [(1, 256), (5, 512), (4099, 256), (3000, 512), (70000, 256), (33, 1024)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_forward_backward(rows, d, residual):
+    from pdanet_amd import pointnet2_utils as pu
+    torch.manual_seed(rows + d)
+    ln = nn.LayerNorm(d).cuda()
+    with torch.no_grad():
+        ln.weight.uniform_(0.5, 1.5); ln.bias.normal_(0, 0.3)
+    x = (torch.randn(rows, d, device="cuda") * 2 + 0.5).requires_grad_(True)
+    r = torch.randn(rows, d, device="cuda", requires_grad=True) if residual else None
+    y = pu.layer_norm(x, ln, residual=r)
+    xd = x.detach().double().requires_grad_(True)
+    rd = r.detach().double().requires_grad_(True) if residual else None
+    yr = F.layer_norm(xd + rd if residual else xd, (d,), ln.weight.double(), ln.bias.double(), ln.eps)
+    assert (y.double() - yr).abs().max().item() < 2e-5
+    go = torch.randn_like(y)
+    ins = [x, ln.weight, ln.bias] + ([r] if residual else [])
+    g = torch.autograd.grad(y, ins, go)
+    wd, bd = ln.weight.detach().double().requires_grad_(True), ln.bias.detach().double().requires_grad_(True)
+    yr = F.layer_norm(xd + rd if residual else xd, (d,), wd, bd, ln.eps)
+    gr = torch.autograd.grad(yr, [xd, wd, bd] + ([rd] if residual else []), go.double())
+    for a, b in zip(g, gr):
+        assert (a.double() - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+
+
+def test_transformer_layer_fused_equals_unfused():
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(5)
+    layer = pm.TransformerEncoderLayerPreNorm(d_model=256, nhead=4, dim_feedforward=128, dropout=0.0).cuda()
+    x = torch.randn(500, 16, 256, device="cuda", requires_grad=True)
+    res = []
+    for flag in (True, False):
+        pm.FUSED_LAYER_NORM = flag
+        y = pm._transformer_batch_first(layer, x)
+        g = torch.autograd.grad(y.square().mean(), [x, layer.norm2.weight, layer.norm1.bias])
+        res.append((y.detach(), g))
+    pm.FUSED_LAYER_NORM = True
+    assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert torch.allclose(a, b, atol=1e-9 + 3e-5 * b.abs().max().item())
