@@ -59,6 +59,16 @@ int pda_layer_norm_bwd(const float *x, const float *grad_y, const float *gamma, 
                        float *grad_x, float *grad_gamma, float *grad_beta, void *scratch, int64_t rows,
                        int d, pda_stream_t stream);
 
+/* ---- weight / bias gradient of a linear layer over a long token axis (MI355X extension) -------------
+ * The backward GEMMs of the point-major 1x1 convolutions and transformer projections: x (tokens, in),
+ * grad_out (tokens, out), both row-major -> grad_weight (out, in) = grad_out^T x (the layout of
+ * nn.Linear.weight / Conv.weight.flatten(1)) and, when grad_bias != NULL, grad_bias (out) = column sums
+ * of grad_out.  Split over the token axis with a fixed-order second stage (deterministic).
+ * in, out: multiples of 4.  scratch: pda_linear_wgrad_scratch_bytes(tokens, in, out) bytes. */
+int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_features);
+int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
+                     void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
+
 /* ---- target assignment ------------------------------------------------------------------------
  * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
  * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],

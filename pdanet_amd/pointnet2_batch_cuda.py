@@ -245,3 +245,15 @@ def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, s
           _chk(mean_rstd, "mean_rstd", F32), _chk(grad_x, "grad_x", F32), _chk(grad_gamma, "grad_gamma", F32),
           _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, d)
     return 1
+
+
+def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_features):
+    """MI355X extension: grad_weight (out, in) = grad_out^T x and grad_bias = column sums (csrc/wgrad.hip)."""
+    _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
+    _numel_ok(grad_weight, in_features * out_features, "grad_weight")
+    nbytes = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    gb = None if grad_bias is None else _chk(grad_bias, "grad_bias", F32)
+    _call("pda_linear_wgrad", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32),
+          gb, _chk(scratch, "scratch", torch.uint8), tokens, in_features, out_features)
+    return 1

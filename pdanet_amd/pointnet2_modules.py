@@ -101,7 +101,7 @@ def _mlp_lastdim(layers, x):
             skip = False
             continue
         if isinstance(m, (nn.Conv2d, nn.Conv1d)):
-            x = F.linear(x, m.weight.flatten(1), m.bias)
+            x = pointnet2_utils.linear(x, m.weight.flatten(1), m.bias)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             if k + 1 < len(layers) and isinstance(layers[k + 1], nn.ReLU):
                 x = _bn_relu_lastdim(m, x)
@@ -126,7 +126,8 @@ def _transformer_batch_first(tr, x):
         src = pointnet2_utils.layer_norm(x, tr.norm1)
     else:
         src = F.layer_norm(x, (D,), tr.norm1.weight, tr.norm1.bias, tr.norm1.eps)
-    qkv = F.linear(src, attn.in_proj_weight, attn.in_proj_bias)
+    lin = pointnet2_utils.linear
+    qkv = lin(src, attn.in_proj_weight, attn.in_proj_bias)
     Bn, S, _ = qkv.shape
     if GROUP_ATTENTION_KERNEL and pointnet2_utils.GroupAttention.supported(qkv, H):
         a = pointnet2_utils.group_attention(qkv, H)              # one wave per (group, head), fp32 MFMA
@@ -134,11 +135,11 @@ def _transformer_batch_first(tr, x):
         q, k, v = qkv.view(Bn, S, 3, H, D // H).permute(2, 0, 3, 1, 4)  # each (Bn, H, S, hd)
         a = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(Bn, S, D)
     if fused_ln:   # LayerNorm(src + out_proj(a)) in one kernel
-        src = pointnet2_utils.layer_norm(F.linear(a, attn.out_proj.weight, attn.out_proj.bias), tr.norm2, residual=src)
+        src = pointnet2_utils.layer_norm(lin(a, attn.out_proj.weight, attn.out_proj.bias), tr.norm2, residual=src)
     else:
-        src = src + F.linear(a, attn.out_proj.weight, attn.out_proj.bias)
+        src = src + lin(a, attn.out_proj.weight, attn.out_proj.bias)
         src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
-    src2 = F.linear(F.relu(F.linear(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)
+    src2 = lin(F.relu(lin(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)
     return src + src2
 
 
@@ -544,7 +545,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             dscale = density / density.max(dim=2, keepdim=True)[0]
             dn = self.point_density[i].densitynet
             for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
-                dscale = _bn_relu_lastdim(bn, F.linear(dscale, conv.weight.flatten(1), conv.bias))
+                dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
             rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)

@@ -290,6 +290,59 @@ def batch_norm_relu(bn, x):
     return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
 
 
+class LinearLongTokens(Function):
+    """y = x W^T + b over the last dim of x (..., in).  Forward and the input gradient are the library GEMMs
+    (F.linear / matmul); the weight and bias gradients -- GEMMs with a tiny output and a reduction over all
+    tokens, which the libraries run at a fraction of their peak -- come from csrc/wgrad.hip in one pass."""
+    MIN_TOKENS = 32768
+
+    @staticmethod
+    def supported(x, weight):
+        """Where the kernel wins on MI355X (profiles/r01_wgrad_microbench.txt): both feature dims >= 128 (its
+        128 x 128 output tile is mostly empty below that) and an output small enough that the tuned library
+        GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 131072 tokens."""
+        if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
+                and torch.is_grad_enabled()):
+            return False
+        n_out, n_in = weight.shape
+        tokens = x.numel() // max(1, x.shape[-1])
+        if n_out % 4 or n_in % 4 or min(n_out, n_in) < 128 or tokens < LinearLongTokens.MIN_TOKENS:
+            return False
+        return n_out * n_in <= 256 * 768 or (n_out * n_in <= 512 * 512 and tokens >= 131072)
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        grad_out = grad_out.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = grad_out.matmul(weight)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            n_out, n_in = weight.shape
+            xc = x.contiguous()
+            tokens = xc.numel() // n_in
+            gw = torch.empty_like(weight)
+            gb = torch.empty((n_out,), dtype=torch.float32, device=x.device) if ctx.has_bias else None
+            pointnet2.linear_wgrad(xc, grad_out, gw, gb, tokens, n_in, n_out)
+        return gx, gw, gb
+
+
+def linear(x, weight, bias=None):
+    """F.linear with the long-token weight-gradient kernel where it applies."""
+    if LINEAR_WGRAD_KERNEL and LinearLongTokens.supported(x, weight):
+        return LinearLongTokens.apply(x, weight, bias)
+    return torch.nn.functional.linear(x, weight, bias)
+
+
+LINEAR_WGRAD_KERNEL = True
+
+
 class LayerNormResidual(Function):
     """MI355X extension: y = LayerNorm(x [+ residual]) over the last dim (csrc/layer_norm.hip); one forward
     kernel, one single-pass backward kernel (+ a tiny fixed-order reduction of the gamma/beta partials)."""
