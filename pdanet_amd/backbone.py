@@ -14,7 +14,7 @@ depends only on coordinates (see `prefetch_fps`).
 import torch
 import torch.nn as nn
 
-from . import pointnet2_modules
+from . import pointnet2_modules, pointnet2_utils
 
 
 class IASSD_Backbone(nn.Module):
@@ -122,6 +122,17 @@ class IASSD_Backbone(nn.Module):
     def forward(self, batch_dict):
         """batch_dict: batch_size, points (B*N, 1 + 3 + C) [bs_idx, x, y, z, ...] with the same N
         for every scene (IASSD_backbone.py:137).  Adds the reference's output keys (:188-203)."""
+        if not self.training:
+            return self._forward(batch_dict)
+        pointnet2_utils.BN_COUNTERS_PENDING = pending = []   # see pointnet2_utils.bump_bn_counter
+        try:
+            return self._forward(batch_dict)
+        finally:
+            pointnet2_utils.BN_COUNTERS_PENDING = None
+            if pending:
+                torch._foreach_add_(pending, 1)
+
+    def _forward(self, batch_dict):
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
         batch_idx, xyz, features = self.break_up_pc(points)

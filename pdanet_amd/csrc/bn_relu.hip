@@ -79,25 +79,25 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
     block_reduce_cols(a, b, lds, s.cg, s.rpb, pa, pa + s.c);
 }
 
-// finalize kernels: grid = ceil(C/64) blocks of 1024 threads = 64 channels x 16 slices of the per-block partials
+// finalize kernels: grid = ceil(C/32) blocks of 512 threads = 32 channels x 16 slices of the per-block partials
 // (a single-thread-per-channel loop over 512 partials would serialise ~1000 dependent loads per layer)
 __device__ __forceinline__ bool sum_partials(const double* __restrict__ partial, int nblocks, int c, double& s1, double& s2, int& ch) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
-    ch = blockIdx.x * 64 + cl;
+    __shared__ double red[2][16][32];
+    const int cl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    ch = blockIdx.x * 32 + cl;
     double a = 0, b = 0;
     if (ch < c) {
-        // BN_BLOCKS / 16 = 32 loads per sum and thread at most: issue them in independent groups of 8
-        double va[8], vb[8];
-        for (int k0 = part; k0 < nblocks; k0 += 16 * 8) {
+        // BN_BLOCKS / 16 = 32 loads per sum and thread: two rounds of 16 independent loads 
+        double va[16], vb[16];
+        for (int k0 = part; k0 < nblocks; k0 += 16 * 16) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < 16; ++u) {
                 const int k = k0 + 16 * u;
                 va[u] = k < nblocks ? partial[(size_t)k * 2 * c + ch] : 0.0;
                 vb[u] = k < nblocks ? partial[(size_t)k * 2 * c + c + ch] : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { a += va[u]; b += vb[u]; }
+            for (int u = 0; u < 16; ++u) { a += va[u]; b += vb[u]; }
         }
     }
     red[0][part][cl] = a; red[1][part][cl] = b;
@@ -110,7 +110,7 @@ __device__ __forceinline__ bool sum_partials(const double* __restrict__ partial,
 }
 
 // forward: mean / invstd (biased variance), running statistics (unbiased variance, momentum)
-__global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
+__global__ __launch_bounds__(512) void bn_finalize_fwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
                                                                float eps, float momentum, float* __restrict__ mean_invstd,
                                                                float* __restrict__ running_mean, float* __restrict__ running_var) {
     double s1, s2;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_fwd_kernel(const double* __r
 }
 
 // backward: dgamma = sum dyh*xhat, dbeta = sum dyh; sums[0][c] = dbeta / rows, sums[1][c] = dgamma / rows
-__global__ __launch_bounds__(1024) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
+__global__ __launch_bounds__(512) void bn_finalize_bwd_kernel(const double* __restrict__ partial, int nblocks, int c, int64_t rows,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                                float* __restrict__ sums) {
     double s1, s2;
@@ -209,7 +209,7 @@ PDA_API int pda_bn_relu_fwd(const float* x, const float* gamma, const float* bet
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pda::bn_reduce_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
-    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 64)), dim3(1024), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
+    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
                        mean_invstd, running_mean, running_var);
     hipLaunchKernelGGL(pda::bn_apply_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, mean_invstd, gamma, beta,
                        (const float*)nullptr, y, s);
@@ -230,7 +230,7 @@ PDA_API int pda_bn_relu_bwd(const float* x, const float* grad_y, const float* ga
     // the per-channel means of the second pass live behind the partials in the scratch buffer
     float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)pda::BN_BLOCKS * 2 * c);
     hipLaunchKernelGGL(pda::bn_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, (double*)scratch, s);
-    hipLaunchKernelGGL(pda::bn_finalize_bwd_kernel, dim3(pda::divup(c, 64)), dim3(1024), 0, st, (const double*)scratch, grid, c, rows, grad_gamma,
+    hipLaunchKernelGGL(pda::bn_finalize_bwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, grad_gamma,
                        grad_beta, sums);
     hipLaunchKernelGGL(pda::bn_apply_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, sums, grad_x, s);
     return pda::check_launch("pda_bn_relu_bwd");

@@ -74,14 +74,14 @@ def _bn_lastdim(bn, x):
     BatchNorm2d over (B, C, H, W) of the channel-major tensor."""
     shp = x.shape
     x4 = x.reshape(shp[0], -1, 1, shp[-1]).permute(0, 3, 1, 2)  # logical (B, C, S, 1), channels_last memory
-    if bn.training and bn.track_running_stats:
-        bn.num_batches_tracked.add_(1)
+    pointnet2_utils.bump_bn_counter(bn)
     y = F.batch_norm(x4, bn.running_mean, bn.running_var, bn.weight, bn.bias,
                      bn.training or bn.running_mean is None, bn.momentum, bn.eps)
     return y.permute(0, 2, 3, 1).reshape(shp)
 
 
 FUSED_BN_RELU = True   # csrc/bn_relu.hip instead of F.batch_norm + F.relu in training mode
+FUSED_TRANSFORMER_BLOCK = True   # the whole encoder layer as one autograd node (pointnet2_utils.TransformerBlock)
 FUSED_LAYER_NORM = True   # csrc/layer_norm.hip (with the residual add fused in) instead of F.layer_norm
 
 
@@ -121,6 +121,9 @@ def _transformer_batch_first(tr, x):
     attn = tr.self_attn
     assert attn.dropout == 0.0 or not tr.training
     D, H = attn.embed_dim, attn.num_heads
+    if (FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL and torch.is_grad_enabled()
+            and pointnet2_utils.TransformerBlock.supported(x, H)):
+        return pointnet2_utils.transformer_block(tr, x)
     fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D)
     if fused_ln:
         src = pointnet2_utils.layer_norm(x, tr.norm1)

@@ -282,10 +282,22 @@ class BatchNormReLU(Function):
         return grad_x, gw, gb, None, None, None, None
 
 
+# num_batches_tracked bookkeeping: 51 one-element `add_` launches per step when every layer bumps its own
+# counter.  IASSD_Backbone.forward collects them here and bumps them with one _foreach_add_ at the end.
+BN_COUNTERS_PENDING = None
+
+
+def bump_bn_counter(bn):
+    if bn.training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if BN_COUNTERS_PENDING is not None:
+            BN_COUNTERS_PENDING.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+
+
 def batch_norm_relu(bn, x):
     """relu(bn(x)) for an nn.BatchNorm{1,2}d module over the LAST dim of x (training mode, fp32)."""
-    if bn.track_running_stats and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+    bump_bn_counter(bn)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
     return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
 
@@ -301,8 +313,11 @@ class LinearLongTokens(Function):
         """Where the kernel wins on MI355X (profiles/r01_wgrad_microbench.txt): both feature dims >= 128 (its
         128 x 128 output tile is mostly empty below that) and an output small enough that the tuned library
         GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 131072 tokens."""
-        if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2
-                and torch.is_grad_enabled()):
+        return torch.is_grad_enabled() and LinearLongTokens.kernel_wins(x, weight)
+
+    @staticmethod
+    def kernel_wins(x, weight):
+        if not (x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and weight.dim() == 2):
             return False
         n_out, n_in = weight.shape
         tokens = x.numel() // max(1, x.shape[-1])
@@ -341,6 +356,101 @@ def linear(x, weight, bias=None):
 
 
 LINEAR_WGRAD_KERNEL = True
+
+
+def _wgrad(x2d, g2d, weight, want_bias):
+    """grad_weight (out, in) and grad_bias of y = x W^T + b from x (T, in), g (T, out): csrc/wgrad.hip where it
+    wins (LinearLongTokens.supported), the library otherwise."""
+    if LINEAR_WGRAD_KERNEL and LinearLongTokens.kernel_wins(x2d, weight):
+        gw = torch.empty_like(weight)
+        gb = torch.empty((weight.shape[0],), dtype=torch.float32, device=x2d.device) if want_bias else None
+        pointnet2.linear_wgrad(x2d, g2d, gw, gb, x2d.shape[0], weight.shape[1], weight.shape[0])
+        return gw, gb
+    return g2d.t().mm(x2d), (g2d.sum(0) if want_bias else None)
+
+
+class TransformerBlock(Function):
+    """TransformerEncoderLayerPreNorm.forward (PointFormer.py:28-38; dropout 0) on x (groups, seq, D) as ONE
+    autograd node with a hand-scheduled backward: LayerNorm and attention on this repo's kernels, the
+    projections on the library GEMMs, weight/bias gradients through `_wgrad`, and the two places where a
+    tensor's gradient is the sum of a residual branch and a projection's input gradient computed by the
+    GEMM itself (addmm, beta = 1) instead of a separate T x D addition pass each."""
+
+    @staticmethod
+    def supported(x, heads):
+        g, s_, d = x.shape
+        return (LayerNormResidual.supported(x, d) and d % heads == 0 and s_ in GroupAttention.SUPPORTED_SEQ
+                and d // heads in GroupAttention.SUPPORTED_HD and not torch.is_autocast_enabled())
+
+    @staticmethod
+    def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2):
+        lin = torch.nn.functional.linear
+        x = x.contiguous()
+        G, S, D = x.shape
+        T, hd = G * S, D // heads
+        dev = x.device
+        src1 = torch.empty_like(x)
+        st1 = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
+        qkv = lin(src1, in_w, in_b)
+        a = torch.empty((G, S, D), dtype=torch.float32, device=dev)
+        lse = torch.empty((G, heads, S), dtype=torch.float32, device=dev)
+        pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
+        proj = lin(a, out_w, out_b)
+        ssum, src2 = torch.empty_like(x), torch.empty_like(x)
+        st2 = torch.empty((T, 2), dtype=torch.float32, device=dev)
+        pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
+        del proj
+        h = torch.relu_(lin(src2, w1, b1))
+        y = src2 + lin(h, w2, b2)
+        ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2)
+        ctx.heads = heads
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2 = ctx.saved_tensors
+        G, S, D = x.shape
+        T, heads = G * S, ctx.heads
+        hd = D // heads
+        dev = x.device
+        dy2 = dy.contiguous().view(T, D)
+        h2 = h.view(T, -1)
+        # y = src2 + h W2^T + b2
+        d_h = dy2.mm(w2)
+        gw2, gb2 = _wgrad(h2, dy2, w2, True)
+        d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
+        # h = relu(src2 W1^T + b1); the residual branch's dy is folded in by the GEMM (beta = 1)
+        gw1, gb1 = _wgrad(src2.view(T, D), d_h, w1, True)
+        d_src2 = torch.addmm(dy2, d_h, w1)
+        del d_h
+        # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
+        d_s = torch.empty((T, D), dtype=torch.float32, device=dev)
+        gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
+        scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
+        pointnet2.layer_norm_bwd(ssum, d_src2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D)
+        del d_src2
+        d_a = d_s.mm(out_w)
+        gwo, gbo = _wgrad(a.view(T, D), d_s, out_w, True)
+        dqkv = torch.empty_like(qkv)
+        pointnet2.group_attention_bwd(qkv, d_a.view(G, S, D), lse, dqkv, G, S, heads, hd)
+        del d_a
+        dqkv2 = dqkv.view(T, 3 * D)
+        gwi, gbi = _wgrad(src1.view(T, D), dqkv2, in_w, True)
+        d_src1 = torch.addmm(d_s, dqkv2, in_w)          # residual gradient d_s + dqkv Win
+        del dqkv, dqkv2, d_s
+        d_x = torch.empty_like(x)
+        gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)
+        pointnet2.layer_norm_bwd(x, d_src1, n1w, st1, d_x, gn1w, gn1b, scratch, T, D)
+        return d_x, gn1w, gn1b, gwi, gbi, gwo, gbo, gn2w, gn2b, gw1, gb1, gw2, gb2, None, None, None
+
+
+def transformer_block(tr, x):
+    """TransformerBlock on the parameters of a TransformerEncoderLayerPreNorm module."""
+    at = tr.self_attn
+    return TransformerBlock.apply(x, tr.norm1.weight, tr.norm1.bias, at.in_proj_weight, at.in_proj_bias, at.out_proj.weight,
+                                  at.out_proj.bias, tr.norm2.weight, tr.norm2.bias, tr.linear1.weight, tr.linear1.bias,
+                                  tr.linear2.weight, tr.linear2.bias, at.num_heads, tr.norm1.eps, tr.norm2.eps)
 
 
 class LayerNormResidual(Function):

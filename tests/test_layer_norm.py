@@ -48,3 +48,24 @@ def test_transformer_layer_fused_equals_unfused():
     assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.allclose(a, b, atol=1e-9 + 3e-5 * b.abs().max().item())
+
+
+@pytest.mark.parametrize("G,S,D,ff", [(300, 16, 256, 128), (2100, 32, 256, 128), (1100, 32, 512, 256)])
+def test_transformer_block_node_equals_op_by_op(G, S, D, ff):
+    """One-node transformer (hand-scheduled backward) == the same layer executed op by op through autograd."""
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(G)
+    layer = pm.TransformerEncoderLayerPreNorm(d_model=D, nhead=4, dim_feedforward=ff, dropout=0.0).cuda()
+    x = torch.randn(G, S, D, device="cuda", requires_grad=True)
+    params = [p for p in layer.parameters()]
+    res = []
+    for flag in (True, False):
+        pm.FUSED_TRANSFORMER_BLOCK = flag
+        y = pm._transformer_batch_first(layer, x)
+        g = torch.autograd.grad(y.square().mean() + y.max(dim=1)[0].sum() * 1e-3, [x] + params)
+        res.append((y.detach(), g))
+    pm.FUSED_TRANSFORMER_BLOCK = True
+    assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
