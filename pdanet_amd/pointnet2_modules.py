@@ -124,7 +124,7 @@ def _transformer_batch_first(tr, x):
     if (FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL and torch.is_grad_enabled()
             and pointnet2_utils.TransformerBlock.supported(x, H)):
         return pointnet2_utils.transformer_block(tr, x)
-    fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D)
+    fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D) and not torch.is_autocast_enabled()
     if fused_ln:
         src = pointnet2_utils.layer_norm(x, tr.norm1)
     else:

@@ -313,7 +313,7 @@ class LinearLongTokens(Function):
         """Where the kernel wins on MI355X (profiles/r01_wgrad_microbench.txt): both feature dims >= 128 (its
         128 x 128 output tile is mostly empty below that) and an output small enough that the tuned library
         GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 131072 tokens."""
-        return torch.is_grad_enabled() and LinearLongTokens.kernel_wins(x, weight)
+        return torch.is_grad_enabled() and not torch.is_autocast_enabled() and LinearLongTokens.kernel_wins(x, weight)
 
     @staticmethod
     def kernel_wins(x, weight):
