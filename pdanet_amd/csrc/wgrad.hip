@@ -21,6 +21,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int WG_KC = 32;       // token rows per LDS chunk
 constexpr int WG_TILE = 128;    // output tile edge
 
+// global_load_lds_dwordx4 as inline asm: with the builtin hipcc (ROCm 7.2) drains vmcnt(0) before the first
+// LDS read that follows, i.e. before the MFMAs the transfer is meant to overlap.  The caller retires the
+// transfers with an explicit s_waitcnt vmcnt(0) before the barrier that precedes the reads of that buffer.
+__device__ __forceinline__ void lds_dma16(const float* gsrc, float* lds_dst_wave_uniform) {
+    uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)lds_dst_wave_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
 __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X, const float* __restrict__ G,
                                                     float* __restrict__ part_w, float* __restrict__ part_b, int64_t T, int M,
                                                     int N, int tiles_m, int tiles_n, int S, int64_t KS, int nblocks) {
@@ -76,29 +86,75 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
         }
     };
 
-    if (t_begin < t_end) {
-        load_chunk(t_begin);
-        store_chunk(0);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int64_t t0 = t_begin; t0 < t_end; t0 += WG_KC) {
-        const bool more = t0 + WG_KC < t_end;
-        if (more) load_chunk(t0 + WG_KC);       // global loads in flight under the MFMAs
+    // Full 128-column tiles take their chunks by LDS-DMA (global_load_lds_dwordx4: one wave instruction lands two
+    // whole 512-byte rows, no VGPR staging, no ds_write pass); the chunk after the one being multiplied is in
+    // flight under the MFMAs.  Ragged tiles / the ragged last chunk of a slice go through registers (zero fill).
+    const bool full_tile = (n0 + WG_TILE <= N) && (m0 + WG_TILE <= M);
+    auto dma_chunk = [&](int64_t t0, int b) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = w * 8 + 2 * i;                                   // this wave instruction: rows row, row + 1
+            const int64_t t = t0 + row + (lane >> 5);
+            const int col = (lane & 31) * 4;
+            lds_dma16(G + t * N + n0 + col, &ldsG[b][row][0]);
+            lds_dma16(X + t * M + m0 + col, &ldsX[b][row][0]);
+        }
+    };
+    auto compute = [&](int buf) {
+        // operand fragments one k-pair ahead of the MFMAs that use them (LDS latency under the MFMA chain)
+        float fa[2][2], fb[2][2];
+        fa[0][0] = ldsG[buf][h][wn * 64 + c]; fa[0][1] = ldsG[buf][h][wn * 64 + 32 + c];
+        fb[0][0] = ldsX[buf][h][wm * 64 + c]; fb[0][1] = ldsX[buf][h][wm * 64 + 32 + c];
 #pragma unroll
         for (int kk = 0; kk < WG_KC / 2; ++kk) {
-            const int k = 2 * kk + h;
-            const float a0 = ldsG[buf][k][wn * 64 + c], a1 = ldsG[buf][k][wn * 64 + 32 + c];
-            const float b0 = ldsX[buf][k][wm * 64 + c], b1 = ldsX[buf][k][wm * 64 + 32 + c];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            bsum[0] += a0; bsum[1] += a1;
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < WG_KC / 2) {
+                const int k = 2 * (kk + 1) + h;
+                fa[nxt][0] = ldsG[buf][k][wn * 64 + c]; fa[nxt][1] = ldsG[buf][k][wn * 64 + 32 + c];
+                fb[nxt][0] = ldsX[buf][k][wm * 64 + c]; fb[nxt][1] = ldsX[buf][k][wm * 64 + 32 + c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][0], fb[cur][1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[cur][1], fb[cur][1], acc[1][1], 0, 0, 0);
+            bsum[0] += fa[cur][0]; bsum[1] += fa[cur][1];
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_chunk(buf ^ 1);
+    };
+
+    int buf = 0;
+    int64_t t0 = t_begin;
+    if (full_tile) {
+        // pure LDS-DMA loop over the whole chunks (kept free of register-staged loads: hipcc drains vmcnt(0) at
+        // any use of an ordinary load's result while a DMA is in flight)
+        const int64_t n_full = (t_end - t_begin) / WG_KC;
+        if (n_full > 0) {
+            dma_chunk(t_begin, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            for (int64_t i = 0; i < n_full; ++i) {
+                if (i + 1 < n_full) dma_chunk(t_begin + (i + 1) * WG_KC, buf ^ 1);
+                compute(buf);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's share of the next chunk has landed
+                __syncthreads();
+                buf ^= 1;
+            }
+            t0 = t_begin + n_full * WG_KC;
+        }
+    }
+    if (t0 < t_end) {                  // ragged tiles, and the ragged last chunk of a slice: through registers
+        load_chunk(t0);
+        store_chunk(buf);
         __syncthreads();
-        buf ^= 1;
+        for (; t0 < t_end; t0 += WG_KC) {
+            const bool more = t0 + WG_KC < t_end;
+            if (more) load_chunk(t0 + WG_KC);
+            compute(buf);
+            if (more) store_chunk(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
     // epilogue: D[row n][col m]: lane (c = m, h), register r -> n = (r & 3) + 8 * (r >> 2) + 4 * h

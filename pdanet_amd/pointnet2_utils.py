@@ -312,7 +312,7 @@ class LinearLongTokens(Function):
     def supported(x, weight):
         """Where the kernel wins on MI355X (profiles/r01_wgrad_microbench.txt): both feature dims >= 128 (its
         128 x 128 output tile is mostly empty below that) and an output small enough that the tuned library
-        GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 131072 tokens."""
+        GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 65536 tokens."""
         return torch.is_grad_enabled() and not torch.is_autocast_enabled() and LinearLongTokens.kernel_wins(x, weight)
 
     @staticmethod
@@ -323,7 +323,7 @@ class LinearLongTokens(Function):
         tokens = x.numel() // max(1, x.shape[-1])
         if n_out % 4 or n_in % 4 or min(n_out, n_in) < 128 or tokens < LinearLongTokens.MIN_TOKENS:
             return False
-        return n_out * n_in <= 256 * 768 or (n_out * n_in <= 512 * 512 and tokens >= 131072)
+        return n_out * n_in <= 256 * 768 or (n_out * n_in <= 512 * 512 and tokens >= 65536)
 
     @staticmethod
     def forward(ctx, x, weight, bias):
