@@ -231,6 +231,10 @@ def main():
                    "parallelism": "dp%d" % world},
         "roofline": roof,
     }
+    if hasattr(wl, "roofline_mfma") and not hasattr(wl, "roofline"):
+        extra = wl.roofline_mfma()
+        if extra is not None:
+            line["roofline_mfma"] = extra      # second own kernel of the step, MFMA-bound (FPS above is latency/HBM)
     if hasattr(wl, "tuned"):
         line["config"]["hipblaslt_tunableop_results_loaded"] = bool(wl.tuned)
     if rank == 0:

@@ -78,6 +78,43 @@ class BackboneWorkload:
             wl.fps_events.append((e0, e1, xyz.shape[1], npoint))
             return out
         pu.furthest_point_sample = pu.farthest_point_sample = timed
+        # ... and the weight-gradient kernel launches (second roofline object: MFMA-bound own kernel)
+        self.wgrad_events = []
+        orig_wg = pu.pointnet2.linear_wgrad
+
+        def timed_wg(x, grad_out, grad_weight, grad_bias, tokens, n_in, n_out):
+            if not wl.record:
+                return orig_wg(x, grad_out, grad_weight, grad_bias, tokens, n_in, n_out)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = orig_wg(x, grad_out, grad_weight, grad_bias, tokens, n_in, n_out)
+            e1.record()
+            wl.wgrad_events.append((e0, e1, tokens, n_in, n_out))
+            return out
+        if not getattr(orig_wg, "_pda_timed", False):
+            timed_wg._pda_timed = True
+            pu.pointnet2.linear_wgrad = timed_wg
+
+    def roofline_mfma(self):
+        """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
+        2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration."""
+        by = {}
+        for e0, e1, t, ni, no in self.wgrad_events:
+            by.setdefault((t, ni, no), []).append(e0.elapsed_time(e1) * 1e-3)
+        if not by:
+            return None
+        (t, ni, no), times = max(by.items(), key=lambda kv: sum(kv[1]))
+        avg = sum(times) / len(times)
+        flops = 2.0 * t * ni * no
+        peak = 157.3
+        total = sum(sum(v) for v in by.values())
+        steps = max(1, len(self.fps_events))          # one D-FPS launch per step
+        return {"kernel": "wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t), "bound": "mfma",
+                "achieved": flops / avg / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / peak,
+                "traffic": None, "avg_launch_ms": avg * 1e3,
+                "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); event-timed launch = split-K kernel + fixed-order "
+                        "second stage; all %d wgrad launches of a step: %.2f ms" % (
+                            sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
 
     @staticmethod
     def loss_of(bd):
