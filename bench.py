@@ -160,6 +160,8 @@ def main():
     from pdanet_amd import parallel
     rank, local_rank, world = parallel.env_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
+    if os.environ.get("PDA_REHEARSE_ONE_GPU") == "1":     # several ranks on one card (with PDA_DIST_BACKEND=gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     parallel.init_distributed("nccl", device)  # backend "nccl" is RCCL on ROCm; no-op for 1 GPU

@@ -24,6 +24,9 @@ def init_distributed(backend=None, device=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
+        # PDA_DIST_BACKEND=gloo: rehearse the multi-process path with several ranks on ONE GPU (RCCL refuses
+        # two ranks on a device; gloo stages CUDA tensors through the host)
+        backend = os.environ.get("PDA_DIST_BACKEND") or backend
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         kwargs = {}
