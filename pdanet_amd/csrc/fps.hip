@@ -348,7 +348,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
 #endif
         if (dirty || __ballot(hit) != 0ull) {
 #ifdef PDA_FPS_STATS
-            if (lane == 0) { atomicAdd(&g_fps_stats[0], 1ull); atomicAdd(&g_fps_stats[2], (unsigned long long)__builtin_popcountll(__ballot(hit))); }
+            const unsigned long long hits_dbg = __ballot(hit);
+            if (lane == 0) { atomicAdd(&g_fps_stats[0], 1ull); atomicAdd(&g_fps_stats[2], (unsigned long long)__builtin_popcountll(hits_dbg)); }
 #endif
             // all P updates are independent; the arg-max is a tree (depth log2 P) that keeps the
             // LOWER slot on equal values (slots are in tie-break order) -- a serial chain of
