@@ -69,6 +69,23 @@ int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
 
+/* ---- DensityNet in training mode (MI355X extension) ----------------------------------------------
+ * pointnet2_modules.py:958-981: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) with 1x1 convs
+ * 1 -> 16 -> 8 -> 1 (with bias), batch statistics over the n tokens; x, y (n) fp32.
+ * params (pda_densitynet_param_count() = 227 floats): w1[16] b1[16] gamma1[16] beta1[16] W2[8][16] b2[8]
+ * gamma2[8] beta2[8] w3[8] b3 gamma3 beta3; grad_params has the same layout.  stats (46 floats) carries the
+ * batch statistics to the backward pass; running_mean/var k (sizes 16, 8, 1) are updated like nn.BatchNorm
+ * (all six NULL: skip).  The input receives no gradient (it is a function of coordinates only).
+ * scratch: pda_densitynet_scratch_bytes() bytes. */
+int pda_densitynet_param_count(void);
+int64_t pda_densitynet_scratch_bytes(void);
+int pda_densitynet_fwd(const float *x, const float *params, float *y, float *stats, void *scratch,
+                       float *running_mean1, float *running_var1, float *running_mean2, float *running_var2,
+                       float *running_mean3, float *running_var3, int64_t n, float eps, float momentum,
+                       pda_stream_t stream);
+int pda_densitynet_bwd(const float *x, const float *grad_y, const float *params, const float *stats,
+                       float *grad_params, void *scratch, int64_t n, float eps, pda_stream_t stream);
+
 /* ---- target assignment ------------------------------------------------------------------------
  * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
  * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],

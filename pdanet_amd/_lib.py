@@ -50,6 +50,10 @@ SIGNATURES = {
     "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_densitynet_param_count": [],
+    "pda_densitynet_scratch_bytes": [],
+    "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],
+    "pda_densitynet_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _vp],
     "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_boxes_overlap_bev": [_vp, _vp, _vp, _i, _i, _vp],
     "pda_boxes_iou_bev": [_vp, _vp, _vp, _i, _i, _vp],
@@ -93,6 +97,7 @@ def load():
     lib.pda_bn_relu_scratch_bytes.restype = ctypes.c_int64
     lib.pda_layer_norm_scratch_bytes.restype = ctypes.c_int64
     lib.pda_linear_wgrad_scratch_bytes.restype = ctypes.c_int64
+    lib.pda_densitynet_scratch_bytes.restype = ctypes.c_int64
     lib.pda_abi_version.restype = _i
     lib.pda_last_error.restype = ctypes.c_char_p
     lib.pda_fp_contract_mode.restype = _i

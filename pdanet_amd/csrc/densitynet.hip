@@ -1,0 +1,415 @@
+// densitynet.hip -- DensityNet (pointnet2_modules.py:958-981) in training mode as 4 + 5 launches
+// (include/pda_train.h): y = relu(bn3(w3 . relu(bn2(W2 relu(bn1(w1 x + b1)) + b2)) + b3)) for a SCALAR input x per
+// (group, neighbour) token, hidden widths 16 and 8, batch statistics over all tokens.
+//
+// Through torch this is 3 x (K<=16 GEMM + bias, BatchNorm statistics / finalise / apply) forward and about 30
+// more launches backward per scale, each a few microseconds of latency-bound work on a (tokens, <=16) tensor.
+// The input is 4 bytes per token, so nothing is materialised here: every pass re-reads x and recomputes the
+// earlier layers in registers.  Forward: P1 sum x, x^2 (layer 1 is affine in x, its batch statistics follow
+// from mean / variance of x); P2 statistics of layer 2's pre-activation; P3 of layer 3's; P4 writes y.
+// Backward (the input has no gradient: it is a function of coordinates only): B1..B4 walk the layers from the
+// last to the first, each pass producing the BatchNorm reduction sums the next one needs plus the weight
+// gradients that have become computable; B5 adds up the last partials.  Per-block partial sums in double,
+// added in fixed order by every block of the following pass (deterministic, no extra finalise launches).
+#include "pda_common.h"
+
+namespace pda {
+
+constexpr int DN_H1 = 16, DN_H2 = 8;
+constexpr int DN_BLOCKS = 64;   // few, fat blocks: every pass starts by adding up the previous pass's per-block partials
+// parameter block (floats): w1[16] b1[16] g1[16] be1[16] W2[8][16] b2[8] g2[8] be2[8] w3[8] b3 g3 be3
+constexpr int DN_W1 = 0, DN_B1 = 16, DN_G1 = 32, DN_BE1 = 48, DN_W2 = 64, DN_B2 = 192, DN_G2 = 200, DN_BE2 = 208,
+              DN_W3 = 216, DN_B3 = 224, DN_G3 = 225, DN_BE3 = 226, DN_NPARAM = 227;
+// statistics block (floats, written by the passes): mx, varx, a1[16] (= w1 g1 / sqrt(w1^2 varx + eps)),
+// mean2[8] inv2[8] mean3 inv3
+// (means are kept as hi + lo float pairs: a mean rounded to float shifts every normalised value by the same
+// ~1e-8, and the backward sums, which cancel to O(eps), pick up n times that)
+constexpr int DN_MX = 0, DN_VX = 1, DN_A1 = 2, DN_M2 = 18, DN_I2 = 26, DN_M3 = 34, DN_I3 = 35, DN_MXL = 36, DN_M2L = 37, DN_M3L = 45,
+              DN_NSTAT = 46;
+// widest partial record of a pass (B3): dW2[128] db2[8] s1[16] s1x[16]
+constexpr int DN_MAXP = 168;
+
+struct DnState {
+    float p[DN_NPARAM];
+};
+
+// block-wide sum of `cnt` per-thread doubles -> partial[blockIdx][k]
+// (a thread sees at most n / 65536 + 1 tokens, so its own running sums stay in float; everything across
+// lanes, waves and blocks is added in double)
+template <int CNT>
+__device__ __forceinline__ void dn_block_partials(const float (&v)[CNT], double* __restrict__ partial) {
+    __shared__ double red[4][CNT];
+    const int lane = lane_id(), w = wave_id();
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        double a = (double)v[k];
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+        if (lane == 0) red[w][k] = a;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < CNT; k += 256) partial[(size_t)blockIdx.x * DN_MAXP + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
+}
+
+// sum over the blocks of the previous pass, fixed order; result in LDS `out[0..cnt)` for all threads
+__device__ __forceinline__ void dn_sum_partials(const double* __restrict__ partial, int nblocks, int cnt, double* out) {
+    __syncthreads();
+    for (int k = threadIdx.x; k < cnt; k += 256) {
+        double a = 0;
+        for (int b0 = 0; b0 < nblocks; b0 += 8) {        // 8 independent loads per round (a serial chain of
+            double v[8];                                  // nblocks dependent L2 round trips costs ~0.5 us each)
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = b0 + u < nblocks ? partial[(size_t)(b0 + u) * DN_MAXP + k] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        out[k] = a;
+    }
+    __syncthreads();
+}
+
+struct DnFwd {  // forward values of one token
+    float xh;                 // x - mean_x
+    float h1[DN_H1];
+    float z2h[DN_H2];         // normalised layer-2 pre-activation
+    float h2[DN_H2];
+    float z3h, y;
+};
+
+__device__ __forceinline__ void dn_layer1(const float* __restrict__ prm, const float* __restrict__ st, float x, DnFwd& f) {
+    f.xh = (x - st[DN_MX]) - st[DN_MXL];
+#pragma unroll
+    for (int c = 0; c < DN_H1; ++c) f.h1[c] = fmaxf(st[DN_A1 + c] * f.xh + prm[DN_BE1 + c], 0.f);
+}
+__device__ __forceinline__ void dn_z2(const float* __restrict__ prm, const DnFwd& f, float (&z2)[DN_H2]) {
+#pragma unroll
+    for (int j = 0; j < DN_H2; ++j) {
+        float a = prm[DN_B2 + j];
+#pragma unroll
+        for (int c = 0; c < DN_H1; ++c) a += prm[DN_W2 + j * DN_H1 + c] * f.h1[c];
+        z2[j] = a;
+    }
+}
+__device__ __forceinline__ float dn_layer2(const float* __restrict__ prm, const float* __restrict__ st, DnFwd& f) {
+    float z2[DN_H2];
+    dn_z2(prm, f, z2);
+    float z3 = prm[DN_B3];
+#pragma unroll
+    for (int j = 0; j < DN_H2; ++j) {
+        f.z2h[j] = ((z2[j] - st[DN_M2 + j]) - st[DN_M2L + j]) * st[DN_I2 + j];
+        f.h2[j] = fmaxf(f.z2h[j] * prm[DN_G2 + j] + prm[DN_BE2 + j], 0.f);
+        z3 += prm[DN_W3 + j] * f.h2[j];
+    }
+    return z3;
+}
+
+__device__ __forceinline__ void dn_running(float* rm, float* rv, int c, double mean, double var, int64_t n, float momentum) {
+    if (!rm) return;
+    const double unbiased = n > 1 ? var * ((double)n / (double)(n - 1)) : var;
+    rm[c] = (float)((1.0 - momentum) * rm[c] + momentum * mean);
+    rv[c] = (float)((1.0 - momentum) * rv[c] + momentum * unbiased);
+}
+
+// PASS: 1 = sum x, x^2; 2 = layer-2 statistics; 3 = layer-3 statistics; 4 = output
+template <int PASS>
+__global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm_g,
+                                                             float* __restrict__ stats, double* __restrict__ part_in,
+                                                             double* __restrict__ part_out, float* __restrict__ y, int64_t n,
+                                                             float eps, float momentum, float* rm1, float* rv1, float* rm2,
+                                                             float* rv2, float* rm3, float* rv3, int nblocks) {
+    __shared__ float prm[DN_NPARAM];
+    __shared__ float st[DN_NSTAT];
+    __shared__ double sums[DN_MAXP];
+    for (int k = threadIdx.x; k < DN_NPARAM; k += 256) prm[k] = prm_g[k];
+    if (PASS >= 3) for (int k = threadIdx.x; k < DN_NSTAT; k += 256) st[k] = stats[k];   // earlier passes' results
+    __syncthreads();
+    // finalise the previous pass's reduction (every block redundantly, block 0 publishes)
+    if (PASS == 2) {
+        dn_sum_partials(part_in, nblocks, 2, sums);
+        const double mx = sums[0] / (double)n;
+        double vx = sums[1] / (double)n - mx * mx;
+        vx = vx < 0 ? 0 : vx;
+        if (threadIdx.x < DN_H1) {
+            const int c = threadIdx.x;
+            const double w = prm[DN_W1 + c];
+            const double var1 = w * w * vx;
+            st[DN_A1 + c] = (float)(w * (double)prm[DN_G1 + c] / sqrt(var1 + (double)eps));
+            if (blockIdx.x == 0) dn_running(rm1, rv1, c, w * mx + (double)prm[DN_B1 + c], var1, n, momentum);
+        }
+        if (threadIdx.x == 0) { st[DN_MX] = (float)mx; st[DN_MXL] = (float)(mx - (double)(float)mx); st[DN_VX] = (float)vx; }
+        __syncthreads();
+        if (blockIdx.x == 0 && threadIdx.x < DN_A1 + DN_H1) stats[threadIdx.x] = st[threadIdx.x];
+        if (blockIdx.x == 0 && threadIdx.x == 0) stats[DN_MXL] = st[DN_MXL];
+    } else if (PASS == 3) {
+        dn_sum_partials(part_in, nblocks, 2 * DN_H2, sums);
+        if (threadIdx.x < DN_H2) {
+            const int j = threadIdx.x;
+            const double m = sums[j] / (double)n;
+            double v = sums[DN_H2 + j] / (double)n - m * m;
+            v = v < 0 ? 0 : v;
+            st[DN_M2 + j] = (float)m;
+            st[DN_M2L + j] = (float)(m - (double)(float)m);
+            st[DN_I2 + j] = (float)(1.0 / sqrt(v + (double)eps));
+            if (blockIdx.x == 0) {
+                dn_running(rm2, rv2, j, m, v, n, momentum);
+                stats[DN_M2 + j] = st[DN_M2 + j]; stats[DN_M2L + j] = st[DN_M2L + j]; stats[DN_I2 + j] = st[DN_I2 + j];
+            }
+        }
+        __syncthreads();
+    } else if (PASS == 4) {
+        dn_sum_partials(part_in, nblocks, 2, sums);
+        if (threadIdx.x == 0) {
+            const double m = sums[0] / (double)n;
+            double v = sums[1] / (double)n - m * m;
+            v = v < 0 ? 0 : v;
+            st[DN_M3] = (float)m;
+            st[DN_M3L] = (float)(m - (double)(float)m);
+            st[DN_I3] = (float)(1.0 / sqrt(v + (double)eps));
+            if (blockIdx.x == 0) { dn_running(rm3, rv3, 0, m, v, n, momentum); stats[DN_M3] = st[DN_M3]; stats[DN_M3L] = st[DN_M3L]; stats[DN_I3] = st[DN_I3]; }
+        }
+        __syncthreads();
+    }
+    constexpr int CNT = PASS == 2 ? 2 * DN_H2 : 2;
+    float acc[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) acc[k] = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const float xv = x[t];
+        if (PASS == 1) {
+            acc[0] += xv; acc[1] += xv * xv;
+        } else {
+            DnFwd f;
+            dn_layer1(prm, st, xv, f);
+            if (PASS == 2) {
+                float z2[DN_H2];
+                dn_z2(prm, f, z2);
+#pragma unroll
+                for (int j = 0; j < DN_H2; ++j) { acc[j] += z2[j]; acc[DN_H2 + j] += z2[j] * z2[j]; }
+            } else {
+                const float z3 = dn_layer2(prm, st, f);
+                if (PASS == 3) { acc[0] += z3; acc[1] += z3 * z3; }
+                else y[t] = fmaxf(((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3] * prm[DN_G3] + prm[DN_BE3], 0.f);
+            }
+        }
+    }
+    if (PASS != 4) dn_block_partials<CNT>(acc, part_out);
+}
+
+// Backward passes.  Partial layouts (doubles):
+//  B1 out: [0] sum dyh3, [1] sum dyh3*z3h
+//  B2 out: dW3[8] @0, db3 @8, s2[8] @9 (sum dyh2), s2z[8] @17 (sum dyh2*z2h)
+//  B3 out: dW2[128] @0, db2[8] @128, s1[16] @136, s1x[16] @152 (sum dyh1 * x1h with x1h = normalised layer-1 input)
+//  B4 out: dW1[16] @0, db1[16] @16
+template <int PASS>
+__global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                             const float* __restrict__ prm_g, const float* __restrict__ stats,
+                                                             const double* __restrict__ p1, const double* __restrict__ p2,
+                                                             const double* __restrict__ p3, double* __restrict__ part_out,
+                                                             int64_t n, float eps, int nblocks) {
+    __shared__ float prm[DN_NPARAM];
+    __shared__ float st[DN_NSTAT];
+    __shared__ double sums[DN_MAXP];
+    // the BatchNorm-backward means stay in double: rounded to float their error enters every token's dz with the
+    // same sign and the weight-gradient sums (ill-conditioned: BN makes them nearly cancel) inherit n times that
+    __shared__ double m3[2], m2[2 * DN_H2], m1[2 * DN_H1];
+    __shared__ float inv1[DN_H1];
+    for (int k = threadIdx.x; k < DN_NPARAM; k += 256) prm[k] = prm_g[k];
+    for (int k = threadIdx.x; k < DN_NSTAT; k += 256) st[k] = stats[k];
+    __syncthreads();
+    if (PASS >= 2) {
+        dn_sum_partials(p1, nblocks, 2, sums);
+        if (threadIdx.x < 2) m3[threadIdx.x] = sums[threadIdx.x] / (double)n;
+    }
+    if (PASS >= 3) {
+        dn_sum_partials(p2, nblocks, 25, sums);
+        if (threadIdx.x < 2 * DN_H2) m2[threadIdx.x] = sums[9 + threadIdx.x] / (double)n;
+    }
+    if (PASS >= 4) {
+        dn_sum_partials(p3, nblocks, DN_MAXP, sums);
+        if (threadIdx.x < 2 * DN_H1) m1[threadIdx.x] = sums[136 + threadIdx.x] / (double)n;
+    }
+    if (threadIdx.x < DN_H1) {
+        // 1 / sqrt(var1 + eps) of layer 1 = a1 / (w1 g1) is ill-conditioned for tiny weights: recompute from var_x
+        const double w = prm[DN_W1 + threadIdx.x];
+        inv1[threadIdx.x] = (float)(1.0 / sqrt(w * w * (double)st[DN_VX] + (double)eps));
+    }
+    __syncthreads();
+    if (PASS == 3) {
+        // dW2 is an 8 x 16 outer-product sum: 128 running sums per token-owning thread would not fit in registers.
+        // Tokens are staged 256 at a time in LDS (h1[16], dz2[8], dyh1[16], xh) and thread k < 168 owns ONE of the
+        // 168 sums of this pass, walking the staged tokens (LDS broadcast reads).
+        __shared__ float stage[256][DN_H1 + DN_H2 + DN_H1 + 1];
+        double mine = 0;
+        const int k = threadIdx.x;
+        for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < n; t0 += (int64_t)gridDim.x * 256) {
+            const int64_t t = t0 + threadIdx.x;
+            float* sp = stage[threadIdx.x];
+            if (t < n) {
+                DnFwd f;
+                dn_layer1(prm, st, x[t], f);
+                const float z3 = dn_layer2(prm, st, f);
+                f.z3h = ((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3];
+                const float dyh3 = (f.z3h * prm[DN_G3] + prm[DN_BE3]) > 0.f ? dy[t] : 0.f;
+                const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - m3[0] - (double)f.z3h * m3[1]);
+                float dz2[DN_H2];
+#pragma unroll
+                for (int j = 0; j < DN_H2; ++j) {
+                    const float dyh2 = f.h2[j] > 0.f ? prm[DN_W3 + j] * dz3 : 0.f;
+                    dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2 - m2[j] - (double)f.z2h[j] * m2[DN_H2 + j]);
+                    sp[DN_H1 + j] = dz2[j];
+                }
+#pragma unroll
+                for (int c = 0; c < DN_H1; ++c) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int j = 0; j < DN_H2; ++j) a += prm[DN_W2 + j * DN_H1 + c] * dz2[j];
+                    sp[c] = f.h1[c];
+                    sp[DN_H1 + DN_H2 + c] = f.h1[c] > 0.f ? a : 0.f;
+                }
+                sp[DN_H1 + DN_H2 + DN_H1] = f.xh;
+            } else {
+#pragma unroll
+                for (int q = 0; q < DN_H1 + DN_H2 + DN_H1 + 1; ++q) sp[q] = 0.f;
+            }
+            __syncthreads();
+            if (k < DN_MAXP) {
+                // double: these sums become the BatchNorm-backward means of the next pass (see m1/m2/m3 above)
+                double a = 0;
+                if (k < 128) {
+                    const int j = k >> 4, c = k & 15;
+                    for (int q = 0; q < 256; ++q) a += (double)(stage[q][DN_H1 + j] * stage[q][c]);
+                } else if (k < 136) {
+                    for (int q = 0; q < 256; ++q) a += (double)stage[q][DN_H1 + (k - 128)];
+                } else if (k < 152) {
+                    for (int q = 0; q < 256; ++q) a += (double)stage[q][DN_H1 + DN_H2 + (k - 136)];
+                } else {
+                    const int c = k - 152;
+                    const float sc = prm[DN_W1 + c] * inv1[c];
+                    for (int q = 0; q < 256; ++q) a += (double)(stage[q][DN_H1 + DN_H2 + c] * (sc * stage[q][DN_H1 + DN_H2 + DN_H1]));
+                }
+                mine += a;
+            }
+            __syncthreads();
+        }
+        if (k < DN_MAXP) part_out[(size_t)blockIdx.x * DN_MAXP + k] = mine;
+        return;
+    }
+    constexpr int CNT = PASS == 1 ? 2 : (PASS == 2 ? 25 : 2 * DN_H1);
+    float acc[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) acc[k] = 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        DnFwd f;
+        dn_layer1(prm, st, x[t], f);
+        const float z3 = dn_layer2(prm, st, f);
+        f.z3h = ((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3];
+        const float yv = f.z3h * prm[DN_G3] + prm[DN_BE3];
+        const float dyh3 = yv > 0.f ? dy[t] : 0.f;
+        if (PASS == 1) { acc[0] += dyh3; acc[1] += dyh3 * f.z3h; continue; }
+        const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - m3[0] - (double)f.z3h * m3[1]);
+        float dyh2[DN_H2];
+#pragma unroll
+        for (int j = 0; j < DN_H2; ++j) dyh2[j] = f.h2[j] > 0.f ? prm[DN_W3 + j] * dz3 : 0.f;
+        if (PASS == 2) {
+#pragma unroll
+            for (int j = 0; j < DN_H2; ++j) { acc[j] += dz3 * f.h2[j]; acc[9 + j] += dyh2[j]; acc[17 + j] += dyh2[j] * f.z2h[j]; }
+            acc[8] += dz3;
+            continue;
+        }
+        // PASS == 4
+        float dz2[DN_H2];
+#pragma unroll
+        for (int j = 0; j < DN_H2; ++j) dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2[j] - m2[j] - (double)f.z2h[j] * m2[DN_H2 + j]);
+#pragma unroll
+        for (int c = 0; c < DN_H1; ++c) {
+            float a = 0.f;
+#pragma unroll
+            for (int j = 0; j < DN_H2; ++j) a += prm[DN_W2 + j * DN_H1 + c] * dz2[j];
+            const float dyh1 = f.h1[c] > 0.f ? a : 0.f;
+            const float x1h = prm[DN_W1 + c] * f.xh * inv1[c];          // normalised layer-1 pre-activation
+            const float dz1 = prm[DN_G1 + c] * inv1[c] * (float)((double)dyh1 - m1[c] - (double)x1h * m1[DN_H1 + c]);
+            acc[c] += dz1 * x[t];
+            acc[DN_H1 + c] += dz1;
+        }
+    }
+    dn_block_partials<CNT>(acc, part_out);
+}
+
+// B5: all parameter gradients, in the layout of the parameter block
+__global__ __launch_bounds__(256) void densitynet_grads_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
+                                                               const double* __restrict__ p3, const double* __restrict__ p4,
+                                                               float* __restrict__ grads, int nblocks) {
+    __shared__ double sums[DN_MAXP];
+    dn_sum_partials(p1, nblocks, 2, sums);
+    if (threadIdx.x == 0) { grads[DN_BE3] = (float)sums[0]; grads[DN_G3] = (float)sums[1]; }
+    dn_sum_partials(p2, nblocks, 25, sums);
+    if (threadIdx.x < DN_H2) {
+        grads[DN_W3 + threadIdx.x] = (float)sums[threadIdx.x];
+        grads[DN_BE2 + threadIdx.x] = (float)sums[9 + threadIdx.x];
+        grads[DN_G2 + threadIdx.x] = (float)sums[17 + threadIdx.x];
+    }
+    if (threadIdx.x == 0) grads[DN_B3] = (float)sums[8];
+    dn_sum_partials(p3, nblocks, DN_MAXP, sums);
+    if (threadIdx.x < DN_H2 * DN_H1) grads[DN_W2 + threadIdx.x] = (float)sums[threadIdx.x];
+    if (threadIdx.x < DN_H2) grads[DN_B2 + threadIdx.x] = (float)sums[128 + threadIdx.x];
+    if (threadIdx.x < DN_H1) {
+        grads[DN_BE1 + threadIdx.x] = (float)sums[136 + threadIdx.x];
+        grads[DN_G1 + threadIdx.x] = (float)sums[152 + threadIdx.x];
+    }
+    dn_sum_partials(p4, nblocks, 2 * DN_H1, sums);
+    if (threadIdx.x < DN_H1) {
+        grads[DN_W1 + threadIdx.x] = (float)sums[threadIdx.x];
+        grads[DN_B1 + threadIdx.x] = (float)sums[DN_H1 + threadIdx.x];
+    }
+}
+
+static int dn_grid(int64_t n) {
+    const int64_t b = divup64(n, 256);
+    return (int)(b < DN_BLOCKS ? b : DN_BLOCKS);
+}
+
+}  // namespace pda
+
+PDA_API int pda_densitynet_param_count(void) { return pda::DN_NPARAM; }
+PDA_API int64_t pda_densitynet_scratch_bytes(void) {
+    return (int64_t)4 * pda::DN_BLOCKS * pda::DN_MAXP * (int64_t)sizeof(double) + pda::DN_NSTAT * (int64_t)sizeof(float);
+}
+
+PDA_API int pda_densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
+                               float* running_var1, float* running_mean2, float* running_var2, float* running_mean3,
+                               float* running_var3, int64_t n, float eps, float momentum, pda_stream_t stream) {
+    PDA_REQUIRE(n >= 1, "pda_densitynet_fwd: n = %lld", (long long)n);
+    PDA_REQUIRE(x && params && y && stats && scratch, "pda_densitynet_fwd: null pointer");
+    const int grid = pda::dn_grid(n);
+    double* pa = (double*)scratch;
+    double* pb = pa + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
+    hipStream_t st = (hipStream_t)stream;
+#define PDA_DN_FWD(P, IN, OUT) hipLaunchKernelGGL(pda::densitynet_fwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, params, stats, IN, OUT, y, n, eps, \
+                                                  momentum, running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3, grid)
+    PDA_DN_FWD(1, (double*)nullptr, pa);
+    PDA_DN_FWD(2, pa, pb);
+    PDA_DN_FWD(3, pb, pa);
+    PDA_DN_FWD(4, pa, (double*)nullptr);
+#undef PDA_DN_FWD
+    return pda::check_launch("pda_densitynet_fwd");
+}
+
+PDA_API int pda_densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
+                               void* scratch, int64_t n, float eps, pda_stream_t stream) {
+    PDA_REQUIRE(n >= 1, "pda_densitynet_bwd: n = %lld", (long long)n);
+    PDA_REQUIRE(x && grad_y && params && stats && grad_params && scratch, "pda_densitynet_bwd: null pointer");
+    const int grid = pda::dn_grid(n);
+    double* p1 = (double*)scratch;
+    double* p2 = p1 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
+    double* p3 = p2 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
+    double* p4 = p3 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
+    hipStream_t st = (hipStream_t)stream;
+#define PDA_DN_BWD(P, OUT) hipLaunchKernelGGL(pda::densitynet_bwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, grad_y, params, stats, p1, p2, p3, OUT, n, eps, grid)
+    PDA_DN_BWD(1, p1);
+    PDA_DN_BWD(2, p2);
+    PDA_DN_BWD(3, p3);
+    PDA_DN_BWD(4, p4);
+#undef PDA_DN_BWD
+    hipLaunchKernelGGL(pda::densitynet_grads_kernel, dim3(1), dim3(256), 0, st, p1, p2, p3, p4, grad_params, grid);
+    return pda::check_launch("pda_densitynet_bwd");
+}

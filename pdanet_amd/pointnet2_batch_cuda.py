@@ -257,3 +257,25 @@ def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_f
     _call("pda_linear_wgrad", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32),
           gb, _chk(scratch, "scratch", torch.uint8), tokens, in_features, out_features)
     return 1
+
+
+def densitynet_sizes():
+    lib = _lib.load()
+    return int(lib.pda_densitynet_param_count()), int(lib.pda_densitynet_scratch_bytes())
+
+
+def densitynet_fwd(x, params, y, stats, scratch, running, n, eps, momentum):
+    """MI355X extension: training-mode DensityNet on a scalar input per token (csrc/densitynet.hip).
+    running: [rm1, rv1, rm2, rv2, rm3, rv3] or None."""
+    _numel_ok(x, n, "x"); _numel_ok(y, n, "y")
+    r = [None] * 6 if running is None else [_chk(t, "running", F32) for t in running]
+    _call("pda_densitynet_fwd", x, _chk(x, "x", F32), _chk(params, "params", F32), _chk(y, "y", F32), _chk(stats, "stats", F32),
+          _chk(scratch, "scratch", torch.uint8), *r, n, float(eps), float(momentum))
+    return 1
+
+
+def densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps):
+    _numel_ok(x, n, "x"); _numel_ok(grad_y, n, "grad_y")
+    _call("pda_densitynet_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(params, "params", F32),
+          _chk(stats, "stats", F32), _chk(grad_params, "grad_params", F32), _chk(scratch, "scratch", torch.uint8), n, float(eps))
+    return 1

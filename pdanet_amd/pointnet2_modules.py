@@ -547,8 +547,11 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             # DensityNet on density / per-group max (:1000-1003); ReLU after every BN (:973-979)
             dscale = density / density.max(dim=2, keepdim=True)[0]
             dn = self.point_density[i].densitynet
-            for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
-                dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
+            if pointnet2_utils.DensityNetFused.supported(dscale, dn):
+                dscale = pointnet2_utils.densitynet(dn, dscale)            # 4 + 5 launches instead of ~45
+            else:
+                for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
+                    dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
             rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)

@@ -302,6 +302,65 @@ def batch_norm_relu(bn, x):
     return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
 
 
+class DensityNetFused(Function):
+    """MI355X extension: DensityNet (1 -> 16 -> 8 -> 1, conv + BatchNorm + ReLU each) in training mode on a scalar
+    input per token, 4 launches forward and 5 backward (csrc/densitynet.hip) instead of ~45 small ones.  The
+    12 parameter tensors travel as one packed 227-float block; their gradients come back the same way."""
+    SPLITS = (16, 16, 16, 16, 128, 8, 8, 8, 8, 1, 1, 1)     # w1 b1 g1 be1 W2 b2 g2 be2 w3 b3 g3 be3
+
+    @staticmethod
+    def supported(x, dn):
+        convs, bns = dn.mlp_convs, dn.mlp_bns
+        return (FUSED_DENSITYNET and x.is_cuda and x.dtype == torch.float32 and not x.requires_grad and dn.training
+                and len(convs) == 3 and [c.out_channels for c in convs] == [16, 8, 1] and convs[0].in_channels == 1
+                and all(c.bias is not None for c in convs) and all(b.affine and b.momentum is not None for b in bns)
+                and len({b.eps for b in bns}) == 1 and len({b.momentum for b in bns}) == 1
+                and not torch.is_autocast_enabled() and x.numel() > 0)
+
+    @staticmethod
+    def forward(ctx, x, eps, momentum, running, *params):
+        x = x.contiguous()
+        n = x.numel()
+        packed = torch.cat([p.reshape(-1) for p in params])
+        nparam, nscratch = pointnet2.densitynet_sizes()
+        assert packed.numel() == nparam
+        y = torch.empty_like(x)
+        stats = torch.empty((46,), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
+        pointnet2.densitynet_fwd(x, packed, y, stats, scratch, running, n, eps, momentum)
+        ctx.save_for_backward(x, packed, stats)
+        ctx.eps = eps
+        ctx.shapes = [p.shape for p in params]
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, packed, stats = ctx.saved_tensors
+        nparam, nscratch = pointnet2.densitynet_sizes()
+        grads = torch.empty((nparam,), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
+        pointnet2.densitynet_bwd(x, grad_y.contiguous(), packed, stats, grads, scratch, x.numel(), ctx.eps)
+        pieces = torch.split(grads, DensityNetFused.SPLITS)
+        return (None, None, None, None) + tuple(g.view(s) for g, s in zip(pieces, ctx.shapes))
+
+
+FUSED_DENSITYNET = True
+
+
+def densitynet(dn, x):
+    """DensityNet module `dn` (pointnet2_modules.DensityNet) on x (..., 1) in training mode."""
+    convs, bns = dn.mlp_convs, dn.mlp_bns
+    running = None
+    if all(b.track_running_stats for b in bns):
+        running = [t for b in bns for t in (b.running_mean, b.running_var)]
+        for b in bns:
+            bump_bn_counter(b)
+    params = []
+    for c, b in zip(convs, bns):
+        params += [c.weight, c.bias, b.weight, b.bias]
+    return DensityNetFused.apply(x, bns[0].eps, bns[0].momentum, running, *params)
+
+
 class LinearLongTokens(Function):
     """y = x W^T + b over the last dim of x (..., in).  Forward and the input gradient are the library GEMMs
     (F.linear / matmul); the weight and bias gradients -- GEMMs with a tiny output and a reduction over all
