@@ -86,6 +86,13 @@ int pda_densitynet_fwd(const float *x, const float *params, float *y, float *sta
 int pda_densitynet_bwd(const float *x, const float *grad_y, const float *params, const float *stats,
                        float *grad_params, void *scratch, int64_t n, float eps, pda_stream_t stream);
 
+/* PDA grouper geometry (MI355X extension; pointnet2_utils.py:590-607, pointnet2_modules.py:905-913,:1000-1001),
+ * point-major: xyz (B,N,3), new_xyz (B,M,3), idx (B,M,nsample) -> rppe (B,M,nsample,12) = [centre, neighbour,
+ * centre - neighbour, (neighbour - centre) / radius] and dscale (B,M,nsample) = gaussian density
+ * exp(-|d|^2 / (2 r^2)) / (2.5 r) divided by its maximum over the group.  nsample: power of two <= 64. */
+int pda_pda_geometry(const float *xyz, const float *new_xyz, const int32_t *idx, float *rppe, float *dscale,
+                     int b, int n, int m, int nsample, float radius, pda_stream_t stream);
+
 /* ---- target assignment ------------------------------------------------------------------------
  * replaces points_in_boxes_gpu (pcdet/ops/roiaware_pool3d/src/roiaware_pool3d.cpp:98-118 ->
  * roiaware_pool3d_kernel.cu:313-359; test :16-36): boxes (B,T,7) [x,y,z,dx,dy,dz,heading],

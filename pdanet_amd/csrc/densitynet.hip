@@ -413,3 +413,54 @@ PDA_API int pda_densitynet_bwd(const float* x, const float* grad_y, const float*
     hipLaunchKernelGGL(pda::densitynet_grads_kernel, dim3(1), dim3(256), 0, st, p1, p2, p3, p4, grad_params, grid);
     return pda::check_launch("pda_densitynet_bwd");
 }
+
+// ---- PDA grouper geometry -------------------------------------------------------------------------------
+// QueryAndGroup_alone_grouped_density_directional (pointnet2_utils.py:590-607) + the relative-position
+// assembly of the PDA layer (pointnet2_modules.py:905-913) + PointConvDensitySetAbstraction's per-group max
+// normalisation (:1000-1001), for the point-major layout: from xyz (B,N,3), centres (B,M,3), idx (B,M,ns):
+//   rppe (B,M,ns,12) = [centre, neighbour, centre - neighbour, (neighbour - centre) / r]
+//   dscale (B,M,ns)  = density / max over the group, density = exp(-|d|^2 / (2 r^2)) / (2.5 r)
+// One thread per (centre, neighbour); the group maximum is a butterfly over the ns lanes of the group.
+// Through torch this is 12 launches over (tokens, 1..12) tensors.  Coordinates carry no gradient.
+namespace pda {
+
+__global__ __launch_bounds__(256) void pda_geometry_kernel(const float* __restrict__ xyz, const float* __restrict__ new_xyz,
+                                                           const int* __restrict__ idx, float* __restrict__ rppe,
+                                                           float* __restrict__ dscale, int n, int m, int ns, int64_t total,
+                                                           float r) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (b, centre, neighbour) flattened; ns | 64 | 256
+    const bool live = e < total;
+    const int64_t ec = live ? e : total - 1;
+    const int64_t bm = ec / ns;
+    const int64_t b = bm / m;
+    const int k = idx[ec];
+    const float* p = xyz + ((size_t)b * n + k) * 3;
+    const float* c = new_xyz + (size_t)bm * 3;
+    const float px = p[0], py = p[1], pz = p[2], cx = c[0], cy = c[1], cz = c[2];
+    const float dx = px - cx, dy = py - cy, dz = pz - cz;
+    const float dist = sqrtf(dx * dx + dy * dy + dz * dz);               // torch.norm
+    const float dens = expf(-(dist * dist) / (2.f * r * r)) / (2.5f * r);
+    float mx = dens;
+    for (int o = ns >> 1; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if (!live) return;
+    dscale[e] = dens / mx;
+    float4* out = reinterpret_cast<float4*>(rppe + (size_t)e * 12);
+    out[0] = make_float4(cx, cy, cz, px);
+    out[1] = make_float4(py, pz, -dx, -dy);
+    out[2] = make_float4(-dz, dx / r, dy / r, dz / r);
+}
+
+}  // namespace pda
+
+PDA_API int pda_pda_geometry(const float* xyz, const float* new_xyz, const int32_t* idx, float* rppe, float* dscale, int b, int n,
+                             int m, int nsample, float radius, pda_stream_t stream) {
+    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && nsample <= 64 && (nsample & (nsample - 1)) == 0,
+                "pda_pda_geometry: b=%d n=%d m=%d nsample=%d (nsample: power of two <= 64)", b, n, m, nsample);
+    const int64_t total = (int64_t)b * m * nsample;
+    if (total == 0) return PDA_OK;
+    PDA_REQUIRE(xyz && new_xyz && idx && rppe && dscale, "pda_pda_geometry: null pointer");
+    PDA_REQUIRE(((uintptr_t)rppe & 15) == 0, "pda_pda_geometry: rppe must be 16-byte aligned");
+    hipLaunchKernelGGL(pda::pda_geometry_kernel, dim3((unsigned)pda::divup64(total, 256)), dim3(256), 0, (hipStream_t)stream, xyz,
+                       new_xyz, idx, rppe, dscale, n, m, nsample, total, radius);
+    return pda::check_launch("pda_pda_geometry");
+}

@@ -279,3 +279,12 @@ def densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps):
     _call("pda_densitynet_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(params, "params", F32),
           _chk(stats, "stats", F32), _chk(grad_params, "grad_params", F32), _chk(scratch, "scratch", torch.uint8), n, float(eps))
     return 1
+
+
+def pda_geometry(xyz, new_xyz, idx, rppe, dscale, b, n, m, nsample, radius):
+    """MI355X extension: relative-position input and normalised gaussian density of a PDA scale (csrc/densitynet.hip)."""
+    _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(idx, b * m * nsample, "idx")
+    _numel_ok(rppe, b * m * nsample * 12, "rppe"); _numel_ok(dscale, b * m * nsample, "dscale")
+    _call("pda_pda_geometry", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32), _chk(idx, "idx", I32),
+          _chk(rppe, "rppe", F32), _chk(dscale, "dscale", F32), b, n, m, nsample, float(radius))
+    return 1

@@ -82,6 +82,7 @@ def _bn_lastdim(bn, x):
 
 FUSED_BN_RELU = True   # csrc/bn_relu.hip instead of F.batch_norm + F.relu in training mode
 FUSED_TRANSFORMER_BLOCK = True   # the whole encoder layer as one autograd node (pointnet2_utils.TransformerBlock)
+FUSED_GEOMETRY = True   # one kernel for the PDA grouper's density / direction / position-encoding input
 FUSED_LAYER_NORM = True   # csrc/layer_norm.hip (with the residual add fused in) instead of F.layer_norm
 
 
@@ -537,23 +538,32 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         outs = []
         for i in range(len(self.groupers)):
             r, ns = self.groupers[i].radius, self.nsamples[i]
-            nbr = pointnet2_utils.group_rows(xyz, idxs[i])                    # (B, M, ns, 3) absolute xyz
             g = pointnet2_utils.group_rows(feats_pm, idxs[i])                 # (B, M, ns, C)
-            diff = nbr - centre
-            # gaussian density exp(-|d|^2 / (2 r^2)) / (2.5 r) and direction d / r (pointnet2_utils.py:594-600)
-            dist = torch.norm(diff, dim=-1, keepdim=True)
-            density = torch.exp(-dist ** 2 / (2 * r ** 2)) / (2.5 * r)        # (B, M, ns, 1)
-            direction = diff / r
-            # DensityNet on density / per-group max (:1000-1003); ReLU after every BN (:973-979)
-            dscale = density / density.max(dim=2, keepdim=True)[0]
+            fused_geo = (FUSED_GEOMETRY and xyz.is_cuda and xyz.dtype == torch.float32 and ns <= 64 and ns & (ns - 1) == 0
+                         and not xyz.requires_grad and not new_xyz.requires_grad)
+            if fused_geo:
+                # [centre, nbr, centre - nbr, direction] (:907-913) and density / per-group max (:594-595,:1000-1001)
+                rppe = torch.empty((B, npoint, ns, 12), dtype=torch.float32, device=xyz.device)
+                dscale = torch.empty((B, npoint, ns, 1), dtype=torch.float32, device=xyz.device)
+                pointnet2_utils.pointnet2.pda_geometry(xyz.contiguous(), new_xyz.contiguous(), idxs[i], rppe, dscale,
+                                                       B, xyz.shape[1], npoint, ns, r)
+            else:
+                nbr = pointnet2_utils.group_rows(xyz, idxs[i])                # (B, M, ns, 3) absolute xyz
+                diff = nbr - centre
+                # gaussian density exp(-|d|^2 / (2 r^2)) / (2.5 r) and direction d / r (pointnet2_utils.py:594-600)
+                dist = torch.norm(diff, dim=-1, keepdim=True)
+                density = torch.exp(-dist ** 2 / (2 * r ** 2)) / (2.5 * r)    # (B, M, ns, 1)
+                direction = diff / r
+                # DensityNet on density / per-group max (:1000-1003); ReLU after every BN (:973-979)
+                dscale = density / density.max(dim=2, keepdim=True)[0]
+                # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
+                rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             dn = self.point_density[i].densitynet
             if pointnet2_utils.DensityNetFused.supported(dscale, dn):
                 dscale = pointnet2_utils.densitynet(dn, dscale)            # 4 + 5 launches instead of ~45
             else:
                 for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
                     dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
-            # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
-            rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
             x = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)  # (B, M, ns, 4C)

@@ -38,3 +38,24 @@ def test_fused_densitynet_matches_module(shape):
         assert torch.allclose(b1.running_mean.double(), b2.running_mean, atol=1e-6)
         assert torch.allclose(b1.running_var.double(), b2.running_var, atol=1e-6, rtol=1e-5)
         assert int(b1.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("B,N,M,ns,r", [(1, 50, 7, 16, 0.8), (2, 4096, 1000, 32, 1.6), (3, 300, 129, 8, 4.8)])
+def test_pda_geometry_kernel_matches_torch_expression(B, N, M, ns, r):
+    from pdanet_amd import pointnet2_batch_cuda as ext, pointnet2_utils as pu
+    torch.manual_seed(N + ns)
+    xyz = torch.randn(B, N, 3, device="cuda") * 2
+    new_xyz = xyz[:, :M].contiguous() + 0.01
+    idx = torch.randint(0, N, (B, M, ns), device="cuda", dtype=torch.int32)
+    rppe = torch.empty(B, M, ns, 12, device="cuda")
+    dscale = torch.empty(B, M, ns, 1, device="cuda")
+    ext.pda_geometry(xyz, new_xyz, idx, rppe, dscale, B, N, M, ns, r)
+    nbr = pu.group_rows(xyz, idx)
+    centre = new_xyz.unsqueeze(2)
+    diff = nbr - centre
+    dist = torch.norm(diff, dim=-1, keepdim=True)
+    density = torch.exp(-dist ** 2 / (2 * r ** 2)) / (2.5 * r)
+    want_d = density / density.max(dim=2, keepdim=True)[0]
+    want_r = torch.cat([centre.expand(B, M, ns, 3), nbr, -diff, diff / r], dim=-1)
+    assert torch.allclose(rppe, want_r, rtol=1e-6, atol=1e-6)
+    assert torch.allclose(dscale, want_d, rtol=2e-6, atol=1e-7)
