@@ -16,7 +16,7 @@
 namespace pda {
 
 constexpr int DN_H1 = 16, DN_H2 = 8;
-constexpr int DN_BLOCKS = 64;   // few, fat blocks: every pass starts by adding up the previous pass's per-block partials
+constexpr int DN_BLOCKS = 128;   // few, fat blocks: every pass starts by adding up the previous pass's per-block partials
 // parameter block (floats): w1[16] b1[16] g1[16] be1[16] W2[8][16] b2[8] g2[8] be2[8] w3[8] b3 g3 be3
 constexpr int DN_W1 = 0, DN_B1 = 16, DN_G1 = 32, DN_BE1 = 48, DN_W2 = 64, DN_B2 = 192, DN_G2 = 200, DN_BE2 = 208,
               DN_W3 = 216, DN_B3 = 224, DN_G3 = 225, DN_BE3 = 226, DN_NPARAM = 227;
@@ -51,17 +51,41 @@ __device__ __forceinline__ void dn_block_partials(const float (&v)[CNT], double*
     for (int k = threadIdx.x; k < CNT; k += 256) partial[(size_t)blockIdx.x * DN_MAXP + k] = (red[0][k] + red[1][k]) + (red[2][k] + red[3][k]);
 }
 
+// sums of up to three earlier passes at once: thread k < c1 + c2 + c3 owns one value (fixed order over the blocks)
+__device__ __forceinline__ void dn_sum_partials3(const double* __restrict__ p1, int c1, double* o1, const double* __restrict__ p2, int c2,
+                                                 double* o2, const double* __restrict__ p3, int c3, double* o3, int nblocks) {
+    __syncthreads();
+    int k = threadIdx.x;
+    const double* src = nullptr;
+    double* dst = nullptr;
+    if (k < c1) { src = p1; dst = o1; }
+    else if ((k -= c1) < c2) { src = p2; dst = o2; }
+    else if ((k -= c2) < c3) { src = p3; dst = o3; }
+    if (src) {
+        double a = 0;
+        for (int b0 = 0; b0 < nblocks; b0 += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = b0 + u < nblocks ? src[(size_t)(b0 + u) * DN_MAXP + k] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a += v[u];
+        }
+        dst[k] = a;
+    }
+    __syncthreads();
+}
+
 // sum over the blocks of the previous pass, fixed order; result in LDS `out[0..cnt)` for all threads
 __device__ __forceinline__ void dn_sum_partials(const double* __restrict__ partial, int nblocks, int cnt, double* out) {
     __syncthreads();
     for (int k = threadIdx.x; k < cnt; k += 256) {
         double a = 0;
-        for (int b0 = 0; b0 < nblocks; b0 += 8) {        // 8 independent loads per round (a serial chain of
-            double v[8];                                  // nblocks dependent L2 round trips costs ~0.5 us each)
+        for (int b0 = 0; b0 < nblocks; b0 += 16) {       // 16 independent loads per round (a serial chain of
+            double v[16];                                 // nblocks dependent L2 round trips costs ~0.5 us each)
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = b0 + u < nblocks ? partial[(size_t)(b0 + u) * DN_MAXP + k] : 0.0;
+            for (int u = 0; u < 16; ++u) v[u] = b0 + u < nblocks ? partial[(size_t)(b0 + u) * DN_MAXP + k] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) a += v[u];
+            for (int u = 0; u < 16; ++u) a += v[u];
         }
         out[k] = a;
     }
@@ -216,17 +240,12 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
     for (int k = threadIdx.x; k < DN_NPARAM; k += 256) prm[k] = prm_g[k];
     for (int k = threadIdx.x; k < DN_NSTAT; k += 256) st[k] = stats[k];
     __syncthreads();
-    if (PASS >= 2) {
-        dn_sum_partials(p1, nblocks, 2, sums);
-        if (threadIdx.x < 2) m3[threadIdx.x] = sums[threadIdx.x] / (double)n;
-    }
-    if (PASS >= 3) {
-        dn_sum_partials(p2, nblocks, 25, sums);
-        if (threadIdx.x < 2 * DN_H2) m2[threadIdx.x] = sums[9 + threadIdx.x] / (double)n;
-    }
-    if (PASS >= 4) {
-        dn_sum_partials(p3, nblocks, DN_MAXP, sums);
-        if (threadIdx.x < 2 * DN_H1) m1[threadIdx.x] = sums[136 + threadIdx.x] / (double)n;
+    {
+        __shared__ double s1[2], s2[25];
+        dn_sum_partials3(p1, PASS >= 2 ? 2 : 0, s1, p2, PASS >= 3 ? 25 : 0, s2, p3, PASS >= 4 ? DN_MAXP : 0, sums, nblocks);
+        if (PASS >= 2 && threadIdx.x < 2) m3[threadIdx.x] = s1[threadIdx.x] / (double)n;
+        if (PASS >= 3 && threadIdx.x < 2 * DN_H2) m2[threadIdx.x] = s2[9 + threadIdx.x] / (double)n;
+        if (PASS >= 4 && threadIdx.x < 2 * DN_H1) m1[threadIdx.x] = sums[136 + threadIdx.x] / (double)n;
     }
     if (threadIdx.x < DN_H1) {
         // 1 / sqrt(var1 + eps) of layer 1 = a1 / (w1 g1) is ill-conditioned for tiny weights: recompute from var_x
@@ -274,18 +293,20 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
             __syncthreads();
             if (k < DN_MAXP) {
                 // double: these sums become the BatchNorm-backward means of the next pass (see m1/m2/m3 above)
+                // 8 tokens per step with independent LDS reads (a dependent chain of 256 LDS round trips otherwise)
                 double a = 0;
-                if (k < 128) {
-                    const int j = k >> 4, c = k & 15;
-                    for (int q = 0; q < 256; ++q) a += (double)(stage[q][DN_H1 + j] * stage[q][c]);
-                } else if (k < 136) {
-                    for (int q = 0; q < 256; ++q) a += (double)stage[q][DN_H1 + (k - 128)];
-                } else if (k < 152) {
-                    for (int q = 0; q < 256; ++q) a += (double)stage[q][DN_H1 + DN_H2 + (k - 136)];
-                } else {
-                    const int c = k - 152;
-                    const float sc = prm[DN_W1 + c] * inv1[c];
-                    for (int q = 0; q < 256; ++q) a += (double)(stage[q][DN_H1 + DN_H2 + c] * (sc * stage[q][DN_H1 + DN_H2 + DN_H1]));
+                int ia, ib;            // a token contributes stage[q][ia] * (ib >= 0 ? stage[q][ib] : 1)
+                float sc = 1.f;
+                if (k < 128) { ia = DN_H1 + (k >> 4); ib = k & 15; }
+                else if (k < 136) { ia = DN_H1 + (k - 128); ib = -1; }
+                else if (k < 152) { ia = DN_H1 + DN_H2 + (k - 136); ib = -1; }
+                else { const int c = k - 152; ia = DN_H1 + DN_H2 + c; ib = DN_H1 + DN_H2 + DN_H1; sc = prm[DN_W1 + c] * inv1[c]; }
+                for (int q0 = 0; q0 < 256; q0 += 8) {
+                    float va[8], vb[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) { va[u] = stage[q0 + u][ia]; vb[u] = ib >= 0 ? stage[q0 + u][ib] : 1.f; }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) a += (double)(va[u] * (sc * vb[u]));
                 }
                 mine += a;
             }
