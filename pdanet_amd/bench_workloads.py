@@ -129,7 +129,7 @@ class BackboneWorkload:
         for p in self.model.parameters():
             p.grad = None
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            bd = model({'batch_size': self.B, 'points': self.points})
+            bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         loss = self.loss_of(bd)
         loss.backward()
         return loss
@@ -200,7 +200,7 @@ class BackboneInferWorkload(BackboneWorkload):
     def step(self):
         self.fused_ops.PROFILE = self.sa_events if self.record else None
         with torch.no_grad():
-            bd = self.model({'batch_size': self.B, 'points': self.points})
+            bd = self.model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         self.fused_ops.PROFILE = None
         return bd['centers_features']
 
@@ -255,7 +255,7 @@ class TrainStepWorkload(BackboneWorkload):
         self.sched.step(self.it)
         self.opt.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            bd = model({'batch_size': self.B, 'points': self.points})
+            bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         loss = self.loss_of(bd)
         loss.backward()
         self.opt.step()
@@ -290,7 +290,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         self.sched.step(self.it)
         self.opt.zero_grad()
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt})
+            ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt, 'inputs_resident': True})
         ret['loss'].backward()
         self.opt.step()
         self.it += 1

@@ -252,3 +252,26 @@ def test_inference_forward_captures_into_hipgraph():
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_resident_input_prefetch_gives_identical_results():
+    """batch_dict['inputs_resident'] only changes WHEN the coordinate-only sampling may start (no wait for the
+    current stream), never what it computes."""
+    import torch
+    from pdanet_amd import synth
+    from pdanet_amd.backbone import build_backbone
+    torch.manual_seed(1)
+    model, _ = build_backbone("once_pda_ssd.yaml")
+    model = model.cuda().eval()
+    pts = torch.from_numpy(synth.batch_points(2, 4096, config_id=2)).cuda()
+    torch.cuda.synchronize()
+    outs = []
+    for resident in (False, True, True):
+        with torch.no_grad():
+            bd = model({'batch_size': 2, 'points': pts, 'inputs_resident': resident})
+        outs.append((bd['centers'].clone(), bd['centers_features'].clone(), bd['encoder_xyz'][2].clone()))
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        for a, b in zip(outs[0], o):
+            assert torch.equal(a, b)
