@@ -183,7 +183,9 @@ def main():
     def barrier():
         parallel.barrier(device)
 
-    for _ in range(args.warmup):
+    # two untimed priming steps on top of the W warm-up steps: first-use costs (code-object loading of every
+    # library GEMM, MIOpen find, allocator growth, TunableOp table lookups) must not leak into a run with small W
+    for _ in range(2 + args.warmup):
         wl.step()
     barrier()
     wl.record = True
