@@ -49,15 +49,16 @@ int pda_bn_relu_bwd(const float *x, const float *grad_y, const float *gamma, con
  * nn.LayerNorm(D) of TransformerEncoderLayerPreNorm (PointFormer.py:17-18,29,33): x (rows, D) [+ residual
  * (rows, D), the sum also written to sum_out] -> y = (s - mean) / sqrt(var + eps) * gamma + beta per row
  * (biased variance); mean_rstd (rows, 2) kept for the backward pass, whose x argument is the normalised
- * tensor (x, or sum_out when a residual was added).  grad_x / grad_gamma / grad_beta are fully written.
+ * tensor (x, or sum_out when a residual was added); grad_y2 (may be NULL) is a second incoming gradient
+ * added to grad_y on the fly.  grad_x / grad_gamma / grad_beta are fully written.
  * D in {256, 512, 1024}.  scratch: pda_layer_norm_scratch_bytes(D) bytes. */
 int64_t pda_layer_norm_scratch_bytes(int d);
 int pda_layer_norm_fwd(const float *x, const float *residual, const float *gamma, const float *beta,
                        float *sum_out, float *y, float *mean_rstd, int64_t rows, int d, float eps,
                        pda_stream_t stream);
-int pda_layer_norm_bwd(const float *x, const float *grad_y, const float *gamma, const float *mean_rstd,
-                       float *grad_x, float *grad_gamma, float *grad_beta, void *scratch, int64_t rows,
-                       int d, pda_stream_t stream);
+int pda_layer_norm_bwd(const float *x, const float *grad_y, const float *grad_y2, const float *gamma,
+                       const float *mean_rstd, float *grad_x, float *grad_gamma, float *grad_beta,
+                       void *scratch, int64_t rows, int d, pda_stream_t stream);
 
 /* ---- weight / bias gradient of a linear layer over a long token axis (MI355X extension) -------------
  * The backward GEMMs of the point-major 1x1 convolutions and transformer projections: x (tokens, in),

@@ -47,7 +47,7 @@ SIGNATURES = {
     "pda_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_layer_norm_scratch_bytes": [_i],
     "pda_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],
-    "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
+    "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_densitynet_param_count": [],

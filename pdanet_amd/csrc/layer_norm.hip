@@ -66,10 +66,12 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
     }
 }
 
-template <int V>
+// TWO: the incoming gradient is dy + dy2 (a residual branch and a projection's input gradient), added on the fly
+template <int V, bool TWO>
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             const float* __restrict__ gamma, const float* __restrict__ mean_rstd,
-                                                             float* __restrict__ dx, float* __restrict__ partial, int64_t rows) {
+                                                             const float* __restrict__ dy2, const float* __restrict__ gamma,
+                                                             const float* __restrict__ mean_rstd, float* __restrict__ dx,
+                                                             float* __restrict__ partial, int64_t rows) {
     constexpr int D = 256 * V;
     __shared__ float red[2][4][D];
     const int lane = lane_id(), w = wave_id();
@@ -87,6 +89,10 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __rest
         for (int v = 0; v < V; ++v) {
             const float4 xv = reinterpret_cast<const float4*>(x + r * D)[v * 64 + lane];
             d[v] = reinterpret_cast<const float4*>(dy + r * D)[v * 64 + lane];
+            if (TWO) {
+                const float4 e = reinterpret_cast<const float4*>(dy2 + r * D)[v * 64 + lane];
+                d[v].x += e.x; d[v].y += e.y; d[v].z += e.z; d[v].w += e.w;
+            }
             xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
             sb[v].x += d[v].x; sb[v].y += d[v].y; sb[v].z += d[v].z; sb[v].w += d[v].w;
             sg[v].x += d[v].x * xh[v].x; sg[v].y += d[v].y * xh[v].y; sg[v].z += d[v].z * xh[v].z; sg[v].w += d[v].w * xh[v].w;
@@ -175,20 +181,23 @@ PDA_API int pda_layer_norm_fwd(const float* x, const float* residual, const floa
     return pda::check_launch("pda_layer_norm_fwd");
 }
 
-PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float* gamma, const float* mean_rstd, float* grad_x,
-                               float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int d, pda_stream_t stream) {
+PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float* grad_y2, const float* gamma, const float* mean_rstd,
+                               float* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int d,
+                               pda_stream_t stream) {
     PDA_REQUIRE(rows >= 1, "pda_layer_norm_bwd: rows = %lld", (long long)rows);
     PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "pda_layer_norm_bwd: D = %d (256, 512 or 1024)", d);
     PDA_REQUIRE(x && grad_y && gamma && mean_rstd && grad_x && grad_gamma && grad_beta && scratch, "pda_layer_norm_bwd: null pointer");
-    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)gamma) & 15) == 0,
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_y2 | (uintptr_t)grad_x | (uintptr_t)gamma) & 15) == 0,
                 "pda_layer_norm_bwd: pointers must be 16-byte aligned");
     const int nblocks = pda::ln_grid(rows);
     const dim3 grid(nblocks), block(256);
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)scratch;
-    if (d == 256) hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<1>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
-    else if (d == 512) hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<2>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
-    else hipLaunchKernelGGL(pda::layer_norm_bwd_kernel<4>, grid, block, 0, st, x, grad_y, gamma, mean_rstd, grad_x, partial, rows);
+#define PDA_LN_BWD(V)                                                                                                               \
+    if (grad_y2) hipLaunchKernelGGL((pda::layer_norm_bwd_kernel<V, true>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, partial, rows); \
+    else hipLaunchKernelGGL((pda::layer_norm_bwd_kernel<V, false>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, partial, rows)
+    if (d == 256) { PDA_LN_BWD(1); } else if (d == 512) { PDA_LN_BWD(2); } else { PDA_LN_BWD(4); }
+#undef PDA_LN_BWD
     hipLaunchKernelGGL(pda::layer_norm_finalize_kernel, dim3(pda::divup(d, 64)), dim3(1024), 0, st, partial, nblocks, d, grad_gamma, grad_beta);
     return pda::check_launch("pda_layer_norm_bwd");
 }

@@ -239,9 +239,13 @@ def layer_norm_fwd(x, residual, gamma, beta, sum_out, y, mean_rstd, rows, d, eps
     return 1
 
 
-def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, scratch, rows, d):
+def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, scratch, rows, d, grad_y2=None):
     _numel_ok(x, rows * d, "x"); _numel_ok(grad_y, rows * d, "grad_y"); _numel_ok(grad_x, rows * d, "grad_x")
-    _call("pda_layer_norm_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32),
+    g2 = None
+    if grad_y2 is not None:
+        _numel_ok(grad_y2, rows * d, "grad_y2")
+        g2 = _chk(grad_y2, "grad_y2", F32)
+    _call("pda_layer_norm_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), g2, _chk(gamma, "gamma", F32),
           _chk(mean_rstd, "mean_rstd", F32), _chk(grad_x, "grad_x", F32), _chk(grad_gamma, "grad_gamma", F32),
           _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, d)
     return 1

@@ -432,8 +432,8 @@ class TransformerBlock(Function):
     """TransformerEncoderLayerPreNorm.forward (PointFormer.py:28-38; dropout 0) on x (groups, seq, D) as ONE
     autograd node with a hand-scheduled backward: LayerNorm and attention on this repo's kernels, the
     projections on the library GEMMs, weight/bias gradients through `_wgrad`, and the two places where a
-    tensor's gradient is the sum of a residual branch and a projection's input gradient computed by the
-    GEMM itself (addmm, beta = 1) instead of a separate T x D addition pass each."""
+    tensor's gradient is the sum of a residual branch and a projection's input gradient handled without a
+    separate T x D addition pass (accumulated by the GEMM in place, or summed inside the LayerNorm backward)."""
 
     @staticmethod
     def supported(x, heads):
@@ -479,16 +479,17 @@ class TransformerBlock(Function):
         d_h = dy2.mm(w2)
         gw2, gb2 = _wgrad(h2, dy2, w2, True)
         d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
-        # h = relu(src2 W1^T + b1); the residual branch's dy is folded in by the GEMM (beta = 1)
+        # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
+        # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
         gw1, gb1 = _wgrad(src2.view(T, D), d_h, w1, True)
-        d_src2 = torch.addmm(dy2, d_h, w1)
+        d_lin1 = d_h.mm(w1)
         del d_h
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
         d_s = torch.empty((T, D), dtype=torch.float32, device=dev)
         gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
-        pointnet2.layer_norm_bwd(ssum, d_src2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D)
-        del d_src2
+        pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1)
+        del d_lin1
         d_a = d_s.mm(out_w)
         gwo, gbo = _wgrad(a.view(T, D), d_s, out_w, True)
         dqkv = torch.empty_like(qkv)
@@ -496,8 +497,8 @@ class TransformerBlock(Function):
         del d_a
         dqkv2 = dqkv.view(T, 3 * D)
         gwi, gbi = _wgrad(src1.view(T, D), dqkv2, in_w, True)
-        d_src1 = torch.addmm(d_s, dqkv2, in_w)          # residual gradient d_s + dqkv Win
-        del dqkv, dqkv2, d_s
+        d_src1 = d_s.addmm_(dqkv2, in_w)                # residual gradient d_s + dqkv Win, in place (d_s is ours)
+        del dqkv, dqkv2
         d_x = torch.empty_like(x)
         gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)
         pointnet2.layer_norm_bwd(x, d_src1, n1w, st1, d_x, gn1w, gn1b, scratch, T, D)
