@@ -70,6 +70,15 @@ int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
 
+/* Residual add + max-pool over the tokens of a group (MI355X extension; pointnet2_modules.py:929-931 on the
+ * encoder layer's output): a, b (groups, seq, D) -> out (groups, D) = max over seq of a + b, arg (groups, D)
+ * uint8 = token of the first maximum; pda_max_pool_scatter writes the dense (groups, seq, D) gradient
+ * (grad_out routed to the arg-max token, zeros elsewhere).  seq <= 255, D multiple of 4. */
+int pda_add_max_pool(const float *a, const float *b, float *out, uint8_t *arg, int64_t groups, int seq, int d,
+                     pda_stream_t stream);
+int pda_max_pool_scatter(const float *grad_out, const uint8_t *arg, float *grad_x, int64_t groups, int seq,
+                         int d, pda_stream_t stream);
+
 /* ---- DensityNet in training mode (MI355X extension) ----------------------------------------------
  * pointnet2_modules.py:958-981: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) with 1x1 convs
  * 1 -> 16 -> 8 -> 1 (with bias), batch statistics over the n tokens; x, y (n) fp32.

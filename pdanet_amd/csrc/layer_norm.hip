@@ -201,3 +201,72 @@ PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float*
     hipLaunchKernelGGL(pda::layer_norm_finalize_kernel, dim3(pda::divup(d, 64)), dim3(1024), 0, st, partial, nblocks, d, grad_gamma, grad_beta);
     return pda::check_launch("pda_layer_norm_bwd");
 }
+
+// ---- residual add + max-pool over the tokens of a group -------------------------------------------------
+// The tail of a PDA scale: y = src + ffn (T x D) followed by the max over the nsample tokens of each group
+// (pointnet2_modules.py:929-931).  Fused: y is never written; out (G, D) and the arg-max token (first maximum)
+// for the backward pass, which writes the dense (G, S, D) gradient in one pass (zeros + the routed values).
+namespace pda {
+
+__global__ __launch_bounds__(256) void add_max_pool_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           float* __restrict__ out, uint8_t* __restrict__ arg, int64_t groups,
+                                                           int s, int d4) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (group, 4-channel column)
+    if (e >= groups * d4) return;
+    const int64_t g = e / d4;
+    const int c = (int)(e % d4);
+    const float4* pa = reinterpret_cast<const float4*>(a) + (size_t)g * s * d4 + c;
+    const float4* pb = reinterpret_cast<const float4*>(b) + (size_t)g * s * d4 + c;
+    float4 best = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
+    uchar4 bi = make_uchar4(0, 0, 0, 0);
+    for (int t = 0; t < s; ++t) {
+        const float4 x = pa[(size_t)t * d4], y = pb[(size_t)t * d4];
+        const float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
+        if (v.x > best.x) { best.x = v.x; bi.x = (uint8_t)t; }
+        if (v.y > best.y) { best.y = v.y; bi.y = (uint8_t)t; }
+        if (v.z > best.z) { best.z = v.z; bi.z = (uint8_t)t; }
+        if (v.w > best.w) { best.w = v.w; bi.w = (uint8_t)t; }
+    }
+    reinterpret_cast<float4*>(out)[e] = best;
+    reinterpret_cast<uchar4*>(arg)[e] = bi;
+}
+
+__global__ __launch_bounds__(256) void max_pool_scatter_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg,
+                                                               float* __restrict__ dx, int64_t groups, int s, int d4) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (group, token, 4-channel column)
+    if (e >= groups * s * d4) return;
+    const int c = (int)(e % d4);
+    const int t = (int)((e / d4) % s);
+    const int64_t g = e / ((int64_t)d4 * s);
+    const float4 v = reinterpret_cast<const float4*>(dout)[g * d4 + c];
+    const uchar4 k = reinterpret_cast<const uchar4*>(arg)[g * d4 + c];
+    reinterpret_cast<float4*>(dx)[e] = make_float4(k.x == t ? v.x : 0.f, k.y == t ? v.y : 0.f, k.z == t ? v.z : 0.f, k.w == t ? v.w : 0.f);
+}
+
+}  // namespace pda
+
+PDA_API int pda_add_max_pool(const float* a, const float* b, float* out, uint8_t* arg, int64_t groups, int seq, int d,
+                             pda_stream_t stream) {
+    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "pda_add_max_pool: groups=%lld seq=%d d=%d",
+                (long long)groups, seq, d);
+    if (groups == 0) return PDA_OK;
+    PDA_REQUIRE(a && b && out && arg, "pda_add_max_pool: null pointer");
+    PDA_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0 && ((uintptr_t)arg & 3) == 0, "pda_add_max_pool: alignment");
+    const int64_t n = groups * (d / 4);
+    hipLaunchKernelGGL(pda::add_max_pool_kernel, dim3((unsigned)pda::divup64(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, arg,
+                       groups, seq, d / 4);
+    return pda::check_launch("pda_add_max_pool");
+}
+
+PDA_API int pda_max_pool_scatter(const float* grad_out, const uint8_t* arg, float* grad_x, int64_t groups, int seq, int d,
+                                 pda_stream_t stream) {
+    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "pda_max_pool_scatter: groups=%lld seq=%d d=%d",
+                (long long)groups, seq, d);
+    if (groups == 0) return PDA_OK;
+    PDA_REQUIRE(grad_out && arg && grad_x, "pda_max_pool_scatter: null pointer");
+    PDA_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_x) & 15) == 0 && ((uintptr_t)arg & 3) == 0, "pda_max_pool_scatter: alignment");
+    const int64_t n = groups * seq * (d / 4);
+    hipLaunchKernelGGL(pda::max_pool_scatter_kernel, dim3((unsigned)pda::divup64(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
+                       arg, grad_x, groups, seq, d / 4);
+    return pda::check_launch("pda_max_pool_scatter");
+}

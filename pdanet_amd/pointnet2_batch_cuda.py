@@ -292,3 +292,17 @@ def pda_geometry(xyz, new_xyz, idx, rppe, dscale, b, n, m, nsample, radius):
     _call("pda_pda_geometry", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32), _chk(idx, "idx", I32),
           _chk(rppe, "rppe", F32), _chk(dscale, "dscale", F32), b, n, m, nsample, float(radius))
     return 1
+
+
+def add_max_pool(a, b, out, arg, groups, seq, d):
+    """MI355X extension: out = max over the seq tokens of a + b, arg = first arg-max token (csrc/layer_norm.hip)."""
+    _numel_ok(a, groups * seq * d, "a"); _numel_ok(b, groups * seq * d, "b"); _numel_ok(out, groups * d, "out"); _numel_ok(arg, groups * d, "arg")
+    _call("pda_add_max_pool", a, _chk(a, "a", F32), _chk(b, "b", F32), _chk(out, "out", F32), _chk(arg, "arg", torch.uint8), groups, seq, d)
+    return 1
+
+
+def max_pool_scatter(grad_out, arg, grad_x, groups, seq, d):
+    _numel_ok(grad_out, groups * d, "grad_out"); _numel_ok(arg, groups * d, "arg"); _numel_ok(grad_x, groups * seq * d, "grad_x")
+    _call("pda_max_pool_scatter", grad_out, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8), _chk(grad_x, "grad_x", F32),
+          groups, seq, d)
+    return 1

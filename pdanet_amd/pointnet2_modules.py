@@ -116,15 +116,16 @@ def _mlp_lastdim(layers, x):
     return x
 
 
-def _transformer_batch_first(tr, x):
+def _transformer_batch_first(tr, x, pool=False):
     """TransformerEncoderLayerPreNorm.forward (PointFormer.py:28-38) on x (batch, seq, D) instead of
-    (seq, batch, D), with the module's own parameters; dropout is 0 in PDA-SSD (:632)."""
+    (seq, batch, D), with the module's own parameters; dropout is 0 in PDA-SSD (:632).  pool=True also takes
+    the max over seq (pointnet2_modules.py:931) and returns (batch, D)."""
     attn = tr.self_attn
     assert attn.dropout == 0.0 or not tr.training
     D, H = attn.embed_dim, attn.num_heads
     if (FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL and torch.is_grad_enabled()
             and pointnet2_utils.TransformerBlock.supported(x, H)):
-        return pointnet2_utils.transformer_block(tr, x)
+        return pointnet2_utils.transformer_block(tr, x, pool)
     fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D) and not torch.is_autocast_enabled()
     if fused_ln:
         src = pointnet2_utils.layer_norm(x, tr.norm1)
@@ -144,7 +145,7 @@ def _transformer_batch_first(tr, x):
         src = src + lin(a, attn.out_proj.weight, attn.out_proj.bias)
         src = F.layer_norm(src, (D,), tr.norm2.weight, tr.norm2.bias, tr.norm2.eps)
     src2 = lin(F.relu(lin(src, tr.linear1.weight, tr.linear1.bias)), tr.linear2.weight, tr.linear2.bias)
-    return src + src2
+    return (src + src2).max(dim=1)[0] if pool else src + src2
 
 
 def calc_square_dist(a, b):
@@ -568,8 +569,8 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
             x = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)  # (B, M, ns, 4C)
             D = x.shape[-1]
-            x = _transformer_batch_first(self.Local_pointformer[i], x.view(B * npoint, ns, D))
-            x = x.max(dim=1)[0].view(B, npoint, D)                            # max over nsample (:931)
+            # encoder layer + max over nsample (:931)
+            x = _transformer_batch_first(self.Local_pointformer[i], x.view(B * npoint, ns, D), pool=True).view(B, npoint, D)
             outs.append(_mlp_lastdim(self.fin_conv[i], x))                    # (B, M, mlp[-1])
         new_features = torch.cat(outs, dim=-1)                                # (B, M, sum)
         if self.aggregation_layer is not None:

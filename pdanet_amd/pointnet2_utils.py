@@ -442,7 +442,7 @@ class TransformerBlock(Function):
                 and d // heads in GroupAttention.SUPPORTED_HD and not torch.is_autocast_enabled())
 
     @staticmethod
-    def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2):
+    def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2, pool):
         lin = torch.nn.functional.linear
         x = x.contiguous()
         G, S, D = x.shape
@@ -461,19 +461,30 @@ class TransformerBlock(Function):
         pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
         del proj
         h = torch.relu_(lin(src2, w1, b1))
-        y = src2 + lin(h, w2, b2)
-        ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2)
-        ctx.heads = heads
+        ffn = lin(h, w2, b2)
+        if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
+            y = torch.empty((G, D), dtype=torch.float32, device=dev)
+            arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
+            pointnet2.add_max_pool(src2, ffn, y, arg, G, S, D)
+        else:
+            y = src2 + ffn
+            arg = torch.empty((0,), dtype=torch.uint8, device=dev)
+        ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg)
+        ctx.heads, ctx.pool = heads, pool
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2 = ctx.saved_tensors
+        x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg = ctx.saved_tensors
         G, S, D = x.shape
         T, heads = G * S, ctx.heads
         hd = D // heads
         dev = x.device
-        dy2 = dy.contiguous().view(T, D)
+        if ctx.pool:   # dy is (G, D): route it to the arg-max tokens (dense (T, D) gradient, written once)
+            dy2 = torch.empty((T, D), dtype=torch.float32, device=dev)
+            pointnet2.max_pool_scatter(dy.contiguous(), arg, dy2, G, S, D)
+        else:
+            dy2 = dy.contiguous().view(T, D)
         h2 = h.view(T, -1)
         # y = src2 + h W2^T + b2
         d_h = dy2.mm(w2)
@@ -502,15 +513,16 @@ class TransformerBlock(Function):
         d_x = torch.empty_like(x)
         gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)
         pointnet2.layer_norm_bwd(x, d_src1, n1w, st1, d_x, gn1w, gn1b, scratch, T, D)
-        return d_x, gn1w, gn1b, gwi, gbi, gwo, gbo, gn2w, gn2b, gw1, gb1, gw2, gb2, None, None, None
+        return d_x, gn1w, gn1b, gwi, gbi, gwo, gbo, gn2w, gn2b, gw1, gb1, gw2, gb2, None, None, None, None
 
 
-def transformer_block(tr, x):
-    """TransformerBlock on the parameters of a TransformerEncoderLayerPreNorm module."""
+def transformer_block(tr, x, pool=False):
+    """TransformerBlock on the parameters of a TransformerEncoderLayerPreNorm module; pool=True returns the max over
+    the sequence dimension, (groups, D), instead of (groups, seq, D)."""
     at = tr.self_attn
     return TransformerBlock.apply(x, tr.norm1.weight, tr.norm1.bias, at.in_proj_weight, at.in_proj_bias, at.out_proj.weight,
                                   at.out_proj.bias, tr.norm2.weight, tr.norm2.bias, tr.linear1.weight, tr.linear1.bias,
-                                  tr.linear2.weight, tr.linear2.bias, at.num_heads, tr.norm1.eps, tr.norm2.eps)
+                                  tr.linear2.weight, tr.linear2.bias, at.num_heads, tr.norm1.eps, tr.norm2.eps, pool)
 
 
 class LayerNormResidual(Function):

@@ -69,3 +69,40 @@ def test_transformer_block_node_equals_op_by_op(G, S, D, ff):
     for a, b in zip(res[0][1], res[1][1]):
         assert a.shape == b.shape
         assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
+
+
+@pytest.mark.parametrize("G,S,D", [(7, 16, 256), (1000, 32, 512), (33, 8, 64)])
+def test_add_max_pool_and_scatter(G, S, D):
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(G)
+    a, b = torch.randn(G, S, D, device="cuda"), torch.randn(G, S, D, device="cuda")
+    a[0, 3] = a[0, 5] = 9.0; b[0, 3] = b[0, 5] = 0.0            # a tie: the first maximum wins
+    out = torch.empty(G, D, device="cuda"); arg = torch.empty(G, D, dtype=torch.uint8, device="cuda")
+    ext.add_max_pool(a, b, out, arg, G, S, D)
+    want, idx = (a + b).max(dim=1)
+    assert torch.equal(out, want)
+    assert (arg[0] == 3).all()
+    assert torch.equal(torch.gather(a + b, 1, arg.long().unsqueeze(1)).squeeze(1), want)
+    go = torch.randn(G, D, device="cuda")
+    dx = torch.empty(G, S, D, device="cuda")
+    ext.max_pool_scatter(go, arg, dx, G, S, D)
+    ref = torch.zeros(G, S, D, device="cuda").scatter_(1, arg.long().unsqueeze(1), go.unsqueeze(1))
+    assert torch.equal(dx, ref)
+
+
+def test_transformer_block_with_pool_equals_unfused_max():
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(11)
+    layer = pm.TransformerEncoderLayerPreNorm(d_model=256, nhead=4, dim_feedforward=128, dropout=0.0).cuda()
+    x = torch.randn(700, 16, 256, device="cuda", requires_grad=True)
+    res = []
+    for flag in (True, False):
+        pm.FUSED_TRANSFORMER_BLOCK = flag
+        y = pm._transformer_batch_first(layer, x, pool=True)
+        assert tuple(y.shape) == (700, 256)
+        g = torch.autograd.grad(y.square().mean(), [x, layer.linear2.weight, layer.norm1.weight])
+        res.append((y.detach(), g))
+    pm.FUSED_TRANSFORMER_BLOCK = True
+    assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
