@@ -70,6 +70,18 @@ int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
 
+/* Token assembly of a PDA scale (MI355X extension; pointnet2_modules.py:879-922), point-major:
+ * out (B,M,ns,4C) = [rppe (B,M,ns,C) | f * dscale | f | glob (B,M,C) broadcast over ns] with f = feats (B,N,C)
+ * gathered by idx (B,M,ns) and dscale (B,M,ns) the density score.  The gradient entry writes grad_rppe,
+ * grad_dscale and grad_glob fully and ADDS into grad_feats (B,N,C), which the caller zero-fills.
+ * C in {16, 32, 64, 128, 256}. */
+int pda_assemble_tokens(const float *rppe, const float *dscale, const float *feats, const int32_t *idx,
+                        const float *glob, float *out, int b, int n, int m, int nsample, int c,
+                        pda_stream_t stream);
+int pda_assemble_tokens_grad(const float *grad_out, const float *dscale, const float *feats, const int32_t *idx,
+                             float *grad_rppe, float *grad_dscale, float *grad_feats, float *grad_glob,
+                             int b, int n, int m, int nsample, int c, pda_stream_t stream);
+
 /* Residual add + max-pool over the tokens of a group (MI355X extension; pointnet2_modules.py:929-931 on the
  * encoder layer's output): a, b (groups, seq, D) -> out (groups, D) = max over seq of a + b, arg (groups, D)
  * uint8 = token of the first maximum; pda_max_pool_scatter writes the dense (groups, seq, D) gradient

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_assemble_tokens_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_add_max_pool": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_max_pool_scatter": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_densitynet_param_count": [],

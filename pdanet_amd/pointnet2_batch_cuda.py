@@ -306,3 +306,23 @@ def max_pool_scatter(grad_out, arg, grad_x, groups, seq, d):
     _call("pda_max_pool_scatter", grad_out, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8), _chk(grad_x, "grad_x", F32),
           groups, seq, d)
     return 1
+
+
+def assemble_tokens(rppe, dscale, feats, idx, glob, out, b, n, m, nsample, c):
+    """MI355X extension: [rppe | f*dscale | f | glob] per (centre, neighbour) token (csrc/assemble.hip)."""
+    t = b * m * nsample
+    _numel_ok(rppe, t * c, "rppe"); _numel_ok(dscale, t, "dscale"); _numel_ok(feats, b * n * c, "feats"); _numel_ok(idx, t, "idx")
+    _numel_ok(glob, b * m * c, "glob"); _numel_ok(out, t * 4 * c, "out")
+    _call("pda_assemble_tokens", rppe, _chk(rppe, "rppe", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
+          _chk(idx, "idx", I32), _chk(glob, "glob", F32), _chk(out, "out", F32), b, n, m, nsample, c)
+    return 1
+
+
+def assemble_tokens_grad(grad_out, dscale, feats, idx, grad_rppe, grad_dscale, grad_feats, grad_glob, b, n, m, nsample, c):
+    t = b * m * nsample
+    _numel_ok(grad_out, t * 4 * c, "grad_out"); _numel_ok(grad_rppe, t * c, "grad_rppe"); _numel_ok(grad_dscale, t, "grad_dscale")
+    _numel_ok(grad_feats, b * n * c, "grad_feats"); _numel_ok(grad_glob, b * m * c, "grad_glob")
+    _call("pda_assemble_tokens_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
+          _chk(idx, "idx", I32), _chk(grad_rppe, "grad_rppe", F32), _chk(grad_dscale, "grad_dscale", F32),
+          _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c)
+    return 1

@@ -539,7 +539,6 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         outs = []
         for i in range(len(self.groupers)):
             r, ns = self.groupers[i].radius, self.nsamples[i]
-            g = pointnet2_utils.group_rows(feats_pm, idxs[i])                 # (B, M, ns, C)
             fused_geo = (FUSED_GEOMETRY and xyz.is_cuda and xyz.dtype == torch.float32 and ns <= 64 and ns & (ns - 1) == 0
                          and not xyz.requires_grad and not new_xyz.requires_grad)
             if fused_geo:
@@ -567,7 +566,11 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                     dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
-            x = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)  # (B, M, ns, 4C)
+            if pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
+                x = pointnet2_utils.AssembleTokens.apply(rppe, dscale, feats_pm, idxs[i], glob)   # (B, M, ns, 4C)
+            else:
+                g = pointnet2_utils.group_rows(feats_pm, idxs[i])             # (B, M, ns, C)
+                x = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)
             D = x.shape[-1]
             # encoder layer + max over nsample (:931)
             x = _transformer_batch_first(self.Local_pointformer[i], x.view(B * npoint, ns, D), pool=True).view(B, npoint, D)

@@ -302,6 +302,45 @@ def batch_norm_relu(bn, x):
     return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
 
 
+class AssembleTokens(Function):
+    """MI355X extension: the encoder input of a PDA scale, x (B,M,ns,4C) = [rppe | f*dscale | f | glob], with f =
+    feats_pm (B,N,C) gathered by idx -- one kernel forward, one backward (csrc/assemble.hip) instead of a grouping,
+    a multiply, an expand and a concatenation (and their autograd chain)."""
+
+    @staticmethod
+    def supported(rppe, feats_pm):
+        c = feats_pm.shape[-1]
+        return (FUSED_ASSEMBLE and rppe.is_cuda and rppe.dtype == torch.float32 and feats_pm.dtype == torch.float32
+                and c in (16, 32, 64, 128, 256) and rppe.shape[-1] == c and not torch.is_autocast_enabled())
+
+    @staticmethod
+    def forward(ctx, rppe, dscale, feats_pm, idx, glob):
+        B, M, ns, C = rppe.shape
+        N = feats_pm.shape[1]
+        rppe, dscale, feats_pm, glob = rppe.contiguous(), dscale.contiguous(), feats_pm.contiguous(), glob.contiguous()
+        out = torch.empty((B, M, ns, 4 * C), dtype=torch.float32, device=rppe.device)
+        pointnet2.assemble_tokens(rppe, dscale, feats_pm, idx, glob, out, B, N, M, ns, C)
+        ctx.save_for_backward(dscale, feats_pm, idx)
+        ctx.dims = (B, N, M, ns, C)
+        ctx.mark_non_differentiable(idx)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dscale, feats_pm, idx = ctx.saved_tensors
+        B, N, M, ns, C = ctx.dims
+        dev = grad_out.device
+        g_rppe = torch.empty((B, M, ns, C), dtype=torch.float32, device=dev)
+        g_ds = torch.empty_like(dscale)
+        g_feats = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
+        g_glob = torch.empty((B, M, C), dtype=torch.float32, device=dev)
+        pointnet2.assemble_tokens_grad(grad_out.contiguous(), dscale, feats_pm, idx, g_rppe, g_ds, g_feats, g_glob, B, N, M, ns, C)
+        return g_rppe, g_ds, g_feats, None, g_glob
+
+
+FUSED_ASSEMBLE = True
+
+
 class DensityNetFused(Function):
     """MI355X extension: DensityNet (1 -> 16 -> 8 -> 1, conv + BatchNorm + ReLU each) in training mode on a scalar
     input per token, 4 launches forward and 5 backward (csrc/densitynet.hip) instead of ~45 small ones.  The

@@ -59,3 +59,25 @@ def test_pda_geometry_kernel_matches_torch_expression(B, N, M, ns, r):
     want_r = torch.cat([centre.expand(B, M, ns, 3), nbr, -diff, diff / r], dim=-1)
     assert torch.allclose(rppe, want_r, rtol=1e-6, atol=1e-6)
     assert torch.allclose(dscale, want_d, rtol=2e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("B,N,M,ns,C", [(1, 40, 5, 16, 16), (2, 4096, 1000, 32, 64), (2, 500, 129, 8, 128)])
+def test_token_assembly_matches_torch_chain(B, N, M, ns, C):
+    from pdanet_amd import pointnet2_utils as pu
+    torch.manual_seed(N + C)
+    rppe = torch.randn(B, M, ns, C, device="cuda", requires_grad=True)
+    dscale = torch.rand(B, M, ns, 1, device="cuda", requires_grad=True)
+    feats = torch.randn(B, N, C, device="cuda", requires_grad=True)
+    glob = torch.randn(B, M, C, device="cuda", requires_grad=True)
+    idx = torch.randint(0, N, (B, M, ns), device="cuda", dtype=torch.int32)
+    assert pu.AssembleTokens.supported(rppe, feats)
+    x = pu.AssembleTokens.apply(rppe, dscale, feats, idx, glob)
+    g = pu.group_rows(feats, idx)
+    ref = torch.cat([rppe, g * dscale, g, glob.unsqueeze(2).expand(-1, -1, ns, -1)], dim=-1)
+    assert torch.equal(x, ref)
+    go = torch.randn_like(x)
+    got = torch.autograd.grad(x, [rppe, dscale, feats, glob], go)
+    want = torch.autograd.grad(ref, [rppe, dscale, feats, glob], go)
+    for a, b, name in zip(got, want, ["rppe", "dscale", "feats", "glob"]):
+        assert a.shape == b.shape
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, b.abs().max().item()), name
