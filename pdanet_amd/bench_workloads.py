@@ -95,6 +95,20 @@ class BackboneWorkload:
             timed_wg._pda_timed = True
             pu.pointnet2.linear_wgrad = timed_wg
 
+    @staticmethod
+    def _pmc_traffic(key):
+        import glob
+        import json
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc", "traffic.json"))):
+            try:
+                k = json.load(open(f))["kernels"].get(key)
+                if k:
+                    return k["hbm_bytes_per_launch_mean"]
+            except (OSError, ValueError, KeyError):
+                pass
+        return None
+
     def roofline_mfma(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
         2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration."""
@@ -111,8 +125,8 @@ class BackboneWorkload:
         steps = max(1, len(self.fps_events))          # one D-FPS launch per step
         return {"kernel": "wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t), "bound": "mfma",
                 "achieved": flops / avg / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / peak,
-                "traffic": None, "avg_launch_ms": avg * 1e3,
-                "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); event-timed launch = split-K kernel + fixed-order "
+                "traffic": self._pmc_traffic("pda::wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t)), "avg_launch_ms": avg * 1e3,
+                "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); traffic = committed PMC passes (profiles/r01_pmc);  event-timed launch = split-K kernel + fixed-order "
                         "second stage; all %d wgrad launches of a step: %.2f ms" % (
                             sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
 
