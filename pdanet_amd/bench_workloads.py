@@ -48,8 +48,10 @@ class BackboneWorkload:
             "once%d_b%d_backbone_fwd_bwd" % (n_points, batch)
         self.device = device
         self.cfg_name = cfg
-        self.amp = amp
-        self.dtype = "bf16 dense / f32 ops" if amp else "f32"
+        self.amp = False            # `amp` selects the dense-bf16 mode, not torch.autocast (see pointnet2_utils.DENSE_BF16)
+        from . import pointnet2_utils as _pu
+        _pu.DENSE_BF16 = bool(amp)
+        self.dtype = "bf16 GEMM operands, f32 accumulate / activations / ops" if amp else "f32"
         self.tuned = enable_tuned_gemms() if os.environ.get("PDA_NO_TUNED_GEMMS") != "1" else False
         torch.manual_seed(1234)  # same initial weights on every rank
         model, self.cfg = build_backbone(cfg)

@@ -446,8 +446,80 @@ class LinearLongTokens(Function):
         return gx, gw, gb
 
 
+# ---- "bf16 dense" mode (BASELINE configs[2]: bf16 on the dense layers, operators fp32) -------------------------
+# DENSE_BF16 = True: the large GEMMs (forward and input gradient of the 1x1 convolutions / projections) take bf16
+# operands with fp32 accumulation and fp32 OUTPUT (torch.mm(..., out_dtype=float32)); every activation, statistic,
+# normalisation, attention and the weight gradients stay fp32, so all of this repo's kernels run unchanged.  This is
+# what torch.autocast does to the GEMM operands, without storing bf16 activations.
+DENSE_BF16 = False
+BF16_MIN_TOKENS = 32768     # below this (and for narrow layers) the operand casts cost more than the GEMM saves
+BF16_MIN_FEATURES = 128
+
+
+def _dense_bf16(x, weight=None):
+    if not (DENSE_BF16 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()):
+        return False
+    if x.numel() // max(1, x.shape[-1]) < BF16_MIN_TOKENS:
+        return False
+    return weight is None or min(weight.shape[0], weight.shape[1]) >= BF16_MIN_FEATURES
+
+
+def _mm_nt(x2d, w, bf16):
+    """x2d (T, in) @ w (out, in)^T -> (T, out) fp32."""
+    if bf16:
+        return torch.mm(x2d.to(torch.bfloat16), w.to(torch.bfloat16).t(), out_dtype=torch.float32)
+    return x2d.mm(w.t())
+
+
+def _mm_nn(g2d, w, bf16, acc=None):
+    """g2d (T, out) @ w (out, in) -> (T, in) fp32; acc: a (T, in) fp32 tensor OWNED by the caller to accumulate into."""
+    if bf16:
+        gb, wb = g2d.to(torch.bfloat16), w.to(torch.bfloat16)
+        if acc is not None:
+            return torch.addmm(acc, gb, wb, out_dtype=torch.float32)
+        return torch.mm(gb, wb, out_dtype=torch.float32)
+    if acc is not None:
+        return acc.addmm_(g2d, w)
+    return g2d.mm(w)
+
+
+def _lin(x, w, b, bf16):
+    """linear over the last dim with the dense-mode GEMM."""
+    if not bf16:
+        return torch.nn.functional.linear(x, w, b)
+    y = _mm_nt(x.reshape(-1, x.shape[-1]), w, True)
+    if b is not None:
+        y.add_(b)
+    return y.view(*x.shape[:-1], w.shape[0])
+
+
+class LinearBF16(Function):
+    """y = x W^T + b with bf16 GEMM operands (fp32 accumulate / output) forward and for the input gradient; the
+    weight / bias gradients as in fp32 mode (`_wgrad`: this repo's kernel where it wins) or a bf16 library GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return _lin(x, weight, bias, True)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight = ctx.saved_tensors
+        n_out, n_in = weight.shape
+        g2 = grad_out.reshape(-1, n_out).contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = _mm_nn(g2, weight, True).view(x.shape)
+        if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
+            gw, gb = _wgrad(x.reshape(-1, n_in), g2, weight, ctx.has_bias, True)
+        return gx, gw, gb
+
+
 def linear(x, weight, bias=None):
-    """F.linear with the long-token weight-gradient kernel where it applies."""
+    """F.linear with the long-token weight-gradient kernel where it applies (and bf16 GEMM operands in DENSE_BF16 mode)."""
+    if weight.dim() == 2 and _dense_bf16(x, weight):
+        return LinearBF16.apply(x, weight, bias) if torch.is_grad_enabled() else _lin(x, weight, bias, True)
     if LINEAR_WGRAD_KERNEL and LinearLongTokens.supported(x, weight):
         return LinearLongTokens.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)
@@ -456,14 +528,17 @@ def linear(x, weight, bias=None):
 LINEAR_WGRAD_KERNEL = True
 
 
-def _wgrad(x2d, g2d, weight, want_bias):
+def _wgrad(x2d, g2d, weight, want_bias, bf16=False):
     """grad_weight (out, in) and grad_bias of y = x W^T + b from x (T, in), g (T, out): csrc/wgrad.hip where it
-    wins (LinearLongTokens.supported), the library otherwise."""
+    wins (LinearLongTokens.supported), the library otherwise (a bf16-operand GEMM in dense-bf16 mode)."""
     if LINEAR_WGRAD_KERNEL and LinearLongTokens.kernel_wins(x2d, weight):
         gw = torch.empty_like(weight)
         gb = torch.empty((weight.shape[0],), dtype=torch.float32, device=x2d.device) if want_bias else None
         pointnet2.linear_wgrad(x2d, g2d, gw, gb, x2d.shape[0], weight.shape[1], weight.shape[0])
         return gw, gb
+    if bf16:
+        gw = torch.mm(g2d.to(torch.bfloat16).t(), x2d.to(torch.bfloat16), out_dtype=torch.float32)
+        return gw, (g2d.sum(0) if want_bias else None)
     return g2d.t().mm(x2d), (g2d.sum(0) if want_bias else None)
 
 
@@ -482,7 +557,8 @@ class TransformerBlock(Function):
 
     @staticmethod
     def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2, pool):
-        lin = torch.nn.functional.linear
+        bf16 = _dense_bf16(x)
+        lin = lambda t, w, b: _lin(t, w, b, bf16)  # noqa: E731
         x = x.contiguous()
         G, S, D = x.shape
         T, hd = G * S, D // heads
@@ -509,7 +585,7 @@ class TransformerBlock(Function):
             y = src2 + ffn
             arg = torch.empty((0,), dtype=torch.uint8, device=dev)
         ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg)
-        ctx.heads, ctx.pool = heads, pool
+        ctx.heads, ctx.pool, ctx.bf16 = heads, pool, bf16
         return y
 
     @staticmethod
@@ -526,13 +602,14 @@ class TransformerBlock(Function):
             dy2 = dy.contiguous().view(T, D)
         h2 = h.view(T, -1)
         # y = src2 + h W2^T + b2
-        d_h = dy2.mm(w2)
-        gw2, gb2 = _wgrad(h2, dy2, w2, True)
+        bf16 = ctx.bf16
+        d_h = _mm_nn(dy2, w2, bf16)
+        gw2, gb2 = _wgrad(h2, dy2, w2, True, bf16)
         d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
-        gw1, gb1 = _wgrad(src2.view(T, D), d_h, w1, True)
-        d_lin1 = d_h.mm(w1)
+        gw1, gb1 = _wgrad(src2.view(T, D), d_h, w1, True, bf16)
+        d_lin1 = _mm_nn(d_h, w1, bf16)
         del d_h
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
         d_s = torch.empty((T, D), dtype=torch.float32, device=dev)
@@ -540,14 +617,14 @@ class TransformerBlock(Function):
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1)
         del d_lin1
-        d_a = d_s.mm(out_w)
-        gwo, gbo = _wgrad(a.view(T, D), d_s, out_w, True)
+        d_a = _mm_nn(d_s, out_w, bf16)
+        gwo, gbo = _wgrad(a.view(T, D), d_s, out_w, True, bf16)
         dqkv = torch.empty_like(qkv)
         pointnet2.group_attention_bwd(qkv, d_a.view(G, S, D), lse, dqkv, G, S, heads, hd)
         del d_a
         dqkv2 = dqkv.view(T, 3 * D)
-        gwi, gbi = _wgrad(src1.view(T, D), dqkv2, in_w, True)
-        d_src1 = d_s.addmm_(dqkv2, in_w)                # residual gradient d_s + dqkv Win, in place (d_s is ours)
+        gwi, gbi = _wgrad(src1.view(T, D), dqkv2, in_w, True, bf16)
+        d_src1 = _mm_nn(dqkv2, in_w, bf16, acc=d_s)     # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv, dqkv2
         d_x = torch.empty_like(x)
         gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)

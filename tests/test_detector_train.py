@@ -120,3 +120,34 @@ def test_fused_and_unfused_training_steps_agree():
         assert (ga[n] - gb[n]).abs().max().item() < 2e-2 * scale, n
     for n in ba:
         assert torch.allclose(ba[n], bb[n], atol=1e-5, rtol=1e-3), n
+
+
+def test_dense_bf16_mode_tracks_fp32():
+    """pointnet2_utils.DENSE_BF16: bf16 GEMM operands (fp32 accumulate / outputs) in the 1x1 convolutions and
+    projections, everything else fp32.  Layers 0-1 of the backbone against the fp32 run: bf16-level agreement."""
+    from pdanet_amd import synth, pointnet2_utils as pu
+    from pdanet_amd.backbone import build_backbone
+    B, N = 2, 4096
+    pts = torch.from_numpy(synth.batch_points(B, N, config_id=2, dist="L")).cuda()
+    res = []
+    for flag in (True, False):
+        pu.DENSE_BF16 = flag
+        try:
+            torch.manual_seed(21)
+            model, _ = build_backbone("once_pda_ssd.yaml")
+            model = model.cuda().train()
+            bd = model({'batch_size': B, 'points': pts})
+            feat = bd['encoder_features'][2]
+            loss = feat.pow(2).mean()
+            loss.backward()
+            res.append((float(loss), feat.detach().clone(), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            pu.DENSE_BF16 = False
+    (la, fa, ga), (lb, fb, gb) = res
+    assert la == pytest.approx(lb, rel=2e-2)
+    assert (fa - fb).abs().mean().item() < 2e-2 * fb.abs().mean().item()
+    big = [n for n in gb if gb[n].abs().max().item() > 2e-3]
+    assert len(big) >= 4
+    for n in big:
+        cos = torch.nn.functional.cosine_similarity(ga[n].flatten(), gb[n].flatten(), dim=0).item()
+        assert cos > 0.98, (n, cos)
