@@ -16,10 +16,12 @@ Workloads (--workload):
   backbone           full backbone forward+backward (default; BASELINE's metric).
   backbone_infer     backbone forward, eval BN, fused SA kernel (BASELINE configs[1]).
   train_step         backbone forward+backward + grad clip + adam_onecycle step (csrc/optim.hip).
-  kitti_train_bf16   the same on the KITTI yaml with bf16 autocast (use --batch 4).
+  backbone_bf16      backbone forward+backward in dense-bf16 mode (bf16 GEMM operands, fp32 accumulate/outputs on
+                     the large projections; activations, statistics and all operators fp32).
+  kitti_train_bf16   train_step on the KITTI yaml in dense-bf16 mode (use --batch 4).
   detector_train     backbone + IA-SSD head (target assignment, all losses) + grad clip + adam_onecycle:
                      the reference's whole training iteration on synthetic scenes and boxes.
-  kitti_detector_train_bf16   the same on the KITTI yaml, bf16 autocast (BASELINE configs[2]; --batch 4).
+  kitti_detector_train_bf16   the same on the KITTI yaml in dense-bf16 mode (BASELINE configs[2]; --batch 4).
 """
 import argparse
 import json

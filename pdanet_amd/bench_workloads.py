@@ -248,8 +248,8 @@ class BackboneInferWorkload(BackboneWorkload):
 class TrainStepWorkload(BackboneWorkload):
     """Forward + backward + clip_grad_norm_(10) + adam_onecycle step (pdanet_amd/optimization.py,
     csrc/optim.hip) -- the iteration of tools/train_utils/train_utils.py:34-60 around the backbone.
-    `kitti_train_bf16` is BASELINE configs[2]: KITTI yaml, 4 scenes per GPU, bf16 autocast on the
-    dense layers (operators stay fp32)."""
+    `kitti_train_bf16`: KITTI yaml, 4 scenes per GPU, dense-bf16 mode (pointnet2_utils.DENSE_BF16;
+    operators, activations and statistics stay fp32)."""
 
     OPTIM = dict(OPTIMIZER="adam_onecycle", LR=0.01, WEIGHT_DECAY=0.01, MOMS=[0.95, 0.85], PCT_START=0.4,
                  DIV_FACTOR=10, GRAD_NORM_CLIP=10)   # once/kitti PDA-SSD.yaml OPTIMIZATION
