@@ -15,7 +15,7 @@ def enable_tuned_gemms(path=TUNING_FILE):
     the backward GEMMs of this model (tall-skinny weight gradients with K = 65k-262k tokens).
     PyTorch's TunableOp benchmarks every GEMM shape once and records the fastest solution; the
     recorded choices for the ONCE-16k / batch-2 step (12 min of tuning on one MI355X,
-    `build/gpu33.sh`) are committed and only LOADED here (tuning stays off, unknown shapes use the
+    `tools/tune_gemms.sh`) are committed and only LOADED here (tuning stays off, unknown shapes use the
     default heuristic).  Measured: 78.2 -> 58.3 ms per training step."""
     try:
         import torch.cuda.tunable as tn
