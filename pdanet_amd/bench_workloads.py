@@ -203,8 +203,8 @@ class BackboneInferWorkload(BackboneWorkload):
     """BASELINE configs[1] literally: PDA-SSD backbone FORWARD (eval BatchNorm, no_grad) with
     the fused SA-scale kernel on layers 0 and 5."""
 
-    def __init__(self, batch, n_points, device, rank, world):
-        super().__init__(batch, n_points, device, rank, world, amp=False)
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False):
+        super().__init__(batch, n_points, device, rank, world, amp=dense_bf16)
         from . import fused_ops
         self.fused_ops = fused_ops
         self.name = self.name.replace("fwd_bwd", "fwd_eval_fused")
@@ -327,6 +327,8 @@ def create(name, batch, n_points, device, rank, world):
                                  dataset="kitti")
     if name == "backbone_infer":
         return BackboneInferWorkload(batch, n_points, device, rank, world)
+    if name == "backbone_infer_bf16":
+        return BackboneInferWorkload(batch, n_points, device, rank, world, dense_bf16=True)
     if name == "backbone":
         return BackboneWorkload(batch, n_points, device, rank, world, amp=False)
     if name == "backbone_bf16":
