@@ -447,10 +447,11 @@ class LinearLongTokens(Function):
 
 
 # ---- "bf16 dense" mode (BASELINE configs[2]: bf16 on the dense layers, operators fp32) -------------------------
-# DENSE_BF16 = True: the large GEMMs (forward and input gradient of the 1x1 convolutions / projections) take bf16
-# operands with fp32 accumulation and fp32 OUTPUT (torch.mm(..., out_dtype=float32)); every activation, statistic,
-# normalisation, attention and the weight gradients stay fp32, so all of this repo's kernels run unchanged.  This is
-# what torch.autocast does to the GEMM operands, without storing bf16 activations.
+# DENSE_BF16 = True: the large GEMMs (forward, input gradient and weight gradient of the 1x1 convolutions /
+# projections) take bf16 operands with fp32 accumulation and fp32 OUTPUT (torch.mm(..., out_dtype=float32)); every
+# activation that a kernel of this repo reads, every statistic, normalisation and the attention stay fp32, so all of
+# those kernels run unchanged.  This is what torch.autocast does to the GEMM operands; the only bf16 tensors stored
+# are the GEMM input copies kept for the weight gradients.
 DENSE_BF16 = False
 BF16_MIN_TOKENS = 32768     # below this (and for narrow layers) the operand casts cost more than the GEMM saves
 BF16_MIN_FEATURES = 128
@@ -464,17 +465,21 @@ def _dense_bf16(x, weight=None):
     return weight is None or min(weight.shape[0], weight.shape[1]) >= BF16_MIN_FEATURES
 
 
+def _b16(t):
+    return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
+
+
 def _mm_nt(x2d, w, bf16):
     """x2d (T, in) @ w (out, in)^T -> (T, out) fp32."""
     if bf16:
-        return torch.mm(x2d.to(torch.bfloat16), w.to(torch.bfloat16).t(), out_dtype=torch.float32)
+        return torch.mm(_b16(x2d), _b16(w).t(), out_dtype=torch.float32)
     return x2d.mm(w.t())
 
 
 def _mm_nn(g2d, w, bf16, acc=None):
     """g2d (T, out) @ w (out, in) -> (T, in) fp32; acc: a (T, in) fp32 tensor OWNED by the caller to accumulate into."""
     if bf16:
-        gb, wb = g2d.to(torch.bfloat16), w.to(torch.bfloat16)
+        gb, wb = _b16(g2d), _b16(w)
         if acc is not None:
             return torch.addmm(acc, gb, wb, out_dtype=torch.float32)
         return torch.mm(gb, wb, out_dtype=torch.float32)
@@ -483,36 +488,41 @@ def _mm_nn(g2d, w, bf16, acc=None):
     return g2d.mm(w)
 
 
-def _lin(x, w, b, bf16):
-    """linear over the last dim with the dense-mode GEMM."""
+def _lin(x, w, b, bf16, keep=False):
+    """linear over the last dim with the dense-mode GEMM.  keep=True also returns the GEMM's (T, in) input operand as
+    it was fed (the bf16 copy in dense-bf16 mode): what a backward pass needs for the weight gradient."""
     if not bf16:
-        return torch.nn.functional.linear(x, w, b)
-    y = _mm_nt(x.reshape(-1, x.shape[-1]), w, True)
+        y = torch.nn.functional.linear(x, w, b)
+        return (y, x.reshape(-1, x.shape[-1])) if keep else y
+    xb = _b16(x.reshape(-1, x.shape[-1]))
+    y = _mm_nt(xb, w, True)
     if b is not None:
         y.add_(b)
-    return y.view(*x.shape[:-1], w.shape[0])
+    y = y.view(*x.shape[:-1], w.shape[0])
+    return (y, xb) if keep else y
 
 
 class LinearBF16(Function):
-    """y = x W^T + b with bf16 GEMM operands (fp32 accumulate / output) forward and for the input gradient; the
-    weight / bias gradients as in fp32 mode (`_wgrad`: this repo's kernel where it wins) or a bf16 library GEMM."""
+    """y = x W^T + b with bf16 GEMM operands (fp32 accumulate / output) in the forward, the input gradient and the
+    weight gradient (`_wgrad_bf16`); keeps only the bf16 copy of x for backward."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
-        ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
-        return _lin(x, weight, bias, True)
+        y, xb = _lin(x, weight, bias, True, keep=True)
+        ctx.save_for_backward(xb, weight)
+        ctx.has_bias, ctx.x_shape = bias is not None, x.shape
+        return y
 
     @staticmethod
     def backward(ctx, grad_out):
-        x, weight = ctx.saved_tensors
+        xb, weight = ctx.saved_tensors
         n_out, n_in = weight.shape
-        g2 = grad_out.reshape(-1, n_out).contiguous()
+        g2 = _b16(grad_out.reshape(-1, n_out))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _mm_nn(g2, weight, True).view(x.shape)
+            gx = _mm_nn(g2, weight, True).view(ctx.x_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
-            gw, gb = _wgrad(x.reshape(-1, n_in), g2, weight, ctx.has_bias, True)
+            gw, gb = _wgrad(xb, g2, weight, ctx.has_bias, True)
         return gx, gw, gb
 
 
@@ -528,17 +538,36 @@ def linear(x, weight, bias=None):
 LINEAR_WGRAD_KERNEL = True
 
 
+def _wgrad_bf16(xb, gb, want_bias):
+    """Dense-bf16 weight gradient g^T x over T tokens: a GEMM with a tiny output and a huge reduction, which the
+    library runs at a fraction of its rate as one problem.  Split the tokens into S slabs -- one batched GEMM with S
+    well-shaped (out x T/S) @ (T/S x in) problems, fp32 partials -- and add the S partials (a few MB)."""
+    T, n_in = xb.shape
+    n_out = gb.shape[1]
+    tiles = max(1, (n_in // 128) * (n_out // 128))
+    S = 64
+    while S > 16 and S * tiles > 768:
+        S //= 2
+    while S > 1 and (T % S or T // S < 512):
+        S //= 2
+    if S > 1:
+        gw = torch.bmm(gb.view(S, T // S, n_out).transpose(1, 2), xb.view(S, T // S, n_in), out_dtype=torch.float32).sum(0)
+    else:
+        gw = torch.mm(gb.t(), xb, out_dtype=torch.float32)
+    return gw, (gb.sum(0, dtype=torch.float32) if want_bias else None)
+
+
 def _wgrad(x2d, g2d, weight, want_bias, bf16=False):
-    """grad_weight (out, in) and grad_bias of y = x W^T + b from x (T, in), g (T, out): csrc/wgrad.hip where it
-    wins (LinearLongTokens.supported), the library otherwise (a bf16-operand GEMM in dense-bf16 mode)."""
+    """grad_weight (out, in) and grad_bias of y = x W^T + b from x (T, in), g (T, out).  fp32: csrc/wgrad.hip where it
+    wins (LinearLongTokens.kernel_wins), the library otherwise.  Dense-bf16 mode: bf16 operands (cast here unless the
+    caller already holds the bf16 copies), fp32 accumulation, split over the tokens."""
+    if bf16:
+        return _wgrad_bf16(_b16(x2d), _b16(g2d), want_bias)
     if LINEAR_WGRAD_KERNEL and LinearLongTokens.kernel_wins(x2d, weight):
         gw = torch.empty_like(weight)
         gb = torch.empty((weight.shape[0],), dtype=torch.float32, device=x2d.device) if want_bias else None
         pointnet2.linear_wgrad(x2d, g2d, gw, gb, x2d.shape[0], weight.shape[1], weight.shape[0])
         return gw, gb
-    if bf16:
-        gw = torch.mm(g2d.to(torch.bfloat16).t(), x2d.to(torch.bfloat16), out_dtype=torch.float32)
-        return gw, (g2d.sum(0) if want_bias else None)
     return g2d.t().mm(x2d), (g2d.sum(0) if want_bias else None)
 
 
@@ -558,7 +587,7 @@ class TransformerBlock(Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2, pool):
         bf16 = _dense_bf16(x)
-        lin = lambda t, w, b: _lin(t, w, b, bf16)  # noqa: E731
+        lin = lambda t, w, b: _lin(t, w, b, bf16, keep=True)  # noqa: E731  (y, the GEMM's input operand as fed)
         x = x.contiguous()
         G, S, D = x.shape
         T, hd = G * S, D // heads
@@ -566,17 +595,18 @@ class TransformerBlock(Function):
         src1 = torch.empty_like(x)
         st1 = torch.empty((T, 2), dtype=torch.float32, device=dev)
         pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
-        qkv = lin(src1, in_w, in_b)
+        qkv, src1_s = lin(src1, in_w, in_b)
         a = torch.empty((G, S, D), dtype=torch.float32, device=dev)
         lse = torch.empty((G, heads, S), dtype=torch.float32, device=dev)
         pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
-        proj = lin(a, out_w, out_b)
+        proj, a_s = lin(a, out_w, out_b)
         ssum, src2 = torch.empty_like(x), torch.empty_like(x)
         st2 = torch.empty((T, 2), dtype=torch.float32, device=dev)
         pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
         del proj
-        h = torch.relu_(lin(src2, w1, b1))
-        ffn = lin(h, w2, b2)
+        h, src2_s = lin(src2, w1, b1)
+        h = torch.relu_(h)
+        ffn, h_s = lin(h, w2, b2)
         if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
             y = torch.empty((G, D), dtype=torch.float32, device=dev)
             arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
@@ -584,13 +614,14 @@ class TransformerBlock(Function):
         else:
             y = src2 + ffn
             arg = torch.empty((0,), dtype=torch.uint8, device=dev)
-        ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg)
+        # backward needs src1 / a / src2 only as weight-gradient operands: in dense-bf16 mode their bf16 copies suffice
+        ctx.save_for_backward(x, st1, src1_s, qkv, lse, a_s, ssum, st2, src2_s, h, h_s, n1w, in_w, out_w, n2w, w1, w2, arg)
         ctx.heads, ctx.pool, ctx.bf16 = heads, pool, bf16
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg = ctx.saved_tensors
+        x, st1, src1_s, qkv, lse, a_s, ssum, st2, src2_s, h, h_s, n1w, in_w, out_w, n2w, w1, w2, arg = ctx.saved_tensors
         G, S, D = x.shape
         T, heads = G * S, ctx.heads
         hd = D // heads
@@ -603,27 +634,33 @@ class TransformerBlock(Function):
         h2 = h.view(T, -1)
         # y = src2 + h W2^T + b2
         bf16 = ctx.bf16
-        d_h = _mm_nn(dy2, w2, bf16)
-        gw2, gb2 = _wgrad(h2, dy2, w2, True, bf16)
+        op = _b16 if bf16 else (lambda t: t)    # each gradient is cast once for its two GEMMs
+        dy_g = op(dy2)
+        d_h = _mm_nn(dy_g, w2, bf16)
+        gw2, gb2 = _wgrad(h_s, dy_g, w2, True, bf16)
+        del dy_g
         d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
+        dh_g = op(d_h)
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
-        gw1, gb1 = _wgrad(src2.view(T, D), d_h, w1, True, bf16)
-        d_lin1 = _mm_nn(d_h, w1, bf16)
-        del d_h
+        gw1, gb1 = _wgrad(src2_s, dh_g, w1, True, bf16)
+        d_lin1 = _mm_nn(dh_g, w1, bf16)
+        del d_h, dh_g
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
         d_s = torch.empty((T, D), dtype=torch.float32, device=dev)
         gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1)
         del d_lin1
-        d_a = _mm_nn(d_s, out_w, bf16)
-        gwo, gbo = _wgrad(a.view(T, D), d_s, out_w, True, bf16)
+        ds_g = op(d_s)
+        d_a = _mm_nn(ds_g, out_w, bf16)
+        gwo, gbo = _wgrad(a_s, ds_g, out_w, True, bf16)
+        del ds_g
         dqkv = torch.empty_like(qkv)
         pointnet2.group_attention_bwd(qkv, d_a.view(G, S, D), lse, dqkv, G, S, heads, hd)
         del d_a
-        dqkv2 = dqkv.view(T, 3 * D)
-        gwi, gbi = _wgrad(src1.view(T, D), dqkv2, in_w, True, bf16)
+        dqkv2 = op(dqkv.view(T, 3 * D))
+        gwi, gbi = _wgrad(src1_s, dqkv2, in_w, True, bf16)
         d_src1 = _mm_nn(dqkv2, in_w, bf16, acc=d_s)     # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv, dqkv2
         d_x = torch.empty_like(x)
