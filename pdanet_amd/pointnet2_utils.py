@@ -604,9 +604,14 @@ class TransformerBlock(Function):
         st2 = torch.empty((T, 2), dtype=torch.float32, device=dev)
         pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
         del proj
-        h, src2_s = lin(src2, w1, b1)
-        h = torch.relu_(h)
-        ffn, h_s = lin(h, w2, b2)
+        if bf16:   # h feeds only the next GEMM (and the ReLU mask): bf16 out of the GEMM, bias + ReLU in its epilogue
+            src2_s = _b16(src2.view(T, D))
+            h = h_s = torch._addmm_activation(_b16(b1), src2_s, _b16(w1).t())
+            ffn = _lin(h, w2, b2, True).view(G, S, D)
+        else:
+            h, src2_s = lin(src2, w1, b1)
+            h = torch.relu_(h)
+            ffn, h_s = lin(h, w2, b2)
         if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
             y = torch.empty((G, D), dtype=torch.float32, device=dev)
             arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
@@ -636,11 +641,12 @@ class TransformerBlock(Function):
         bf16 = ctx.bf16
         op = _b16 if bf16 else (lambda t: t)    # each gradient is cast once for its two GEMMs
         dy_g = op(dy2)
-        d_h = _mm_nn(dy_g, w2, bf16)
+        # d_h feeds only GEMMs: in dense-bf16 mode it leaves its GEMM as bf16 (no fp32 round trip, no cast pass)
+        d_h = torch.mm(dy_g, _b16(w2)) if bf16 else dy_g.mm(w2)
         gw2, gb2 = _wgrad(h_s, dy_g, w2, True, bf16)
         del dy_g
         d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
-        dh_g = op(d_h)
+        dh_g = d_h
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
         gw1, gb1 = _wgrad(src2_s, dh_g, w1, True, bf16)
