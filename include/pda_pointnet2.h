@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 7
+#define PDA_POINTNET2_ABI_VERSION 8
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -152,6 +152,14 @@ int pda_group_attention_fwd(const float *qkv, float *out, float *lse, int64_t nu
 int pda_group_attention_bwd(const float *qkv, const float *grad_out, const float *lse,
                             float *grad_qkv, int64_t num_groups, int seq, int heads, int head_dim,
                             pda_stream_t stream);
+/* The same kernels with bf16 tensors at the HBM boundary (raw bf16 bit patterns; lse stays fp32): for the dense-bf16
+ * mode, where qkv / grad_out come straight out of bf16 GEMMs and out / grad_qkv go straight into them.  All arithmetic
+ * (MFMA operands, softmax, accumulation) is fp32 as above; outputs are rounded to nearest even once, on the store. */
+int pda_group_attention_fwd_bf16(const uint16_t *qkv, uint16_t *out, float *lse, int64_t num_groups, int seq,
+                                 int heads, int head_dim, pda_stream_t stream);
+int pda_group_attention_bwd_bf16(const uint16_t *qkv, const uint16_t *grad_out, const float *lse,
+                                 uint16_t *grad_qkv, int64_t num_groups, int seq, int heads, int head_dim,
+                                 pda_stream_t stream);
 
 /* ---- fused set-abstraction scale (MI355X extension) --------------------------------- */
 /* One scale of a vanilla SA layer in inference form, fused into one kernel:

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -36,6 +36,8 @@ SIGNATURES = {
     "pda_chamfer_backward": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_group_attention_fwd": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_group_attention_bwd": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
+    "pda_group_attention_fwd_bf16": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
+    "pda_group_attention_bwd_bf16": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_sa_mlp_maxpool": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),
                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],

@@ -30,6 +30,30 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
+// Tensor element type at the HBM boundary: float, or bf16 (raw uint16_t) in the dense-bf16 mode, where qkv / dout come
+// straight out of bf16 GEMMs and out / dqkv go straight into them.  All arithmetic is fp32 either way.
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float((uint32_t)u << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
+    const uint32_t b = __float_as_uint(f);
+    return (f != f) ? (bf16_t)0x7fc0 : (bf16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+
 template <int HD>
 struct GaPtrs {
     // element (b, s, which, head, d) of qkv (Bn, S, 3, H, HD)
@@ -58,8 +82,8 @@ struct Tile {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             bool valid;
-            const float* p = row_ptr(it * RPI + lane / LPR, valid);  // always dereferenceable (clamped)
-            const float4 v = *reinterpret_cast<const float4*>(p + 4 * (lane % LPR));
+            const auto* p = row_ptr(it * RPI + lane / LPR, valid);  // always dereferenceable (clamped)
+            const float4 v = load4(p + 4 * (lane % LPR));
             raw[it] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -87,18 +111,18 @@ struct Tile {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int r = it * RPI + lane / LPR;
-            float* p = row_ptr(r);
+            auto* p = row_ptr(r);
             const float4 v = *reinterpret_cast<const float4*>(lds + r * LD + 4 * (lane % LPR));
-            if (p) *reinterpret_cast<float4*>(p + 4 * (lane % LPR)) = v;
+            if (p) store4(p + 4 * (lane % LPR), v);
         }
     }
 };
 
 // S: tokens per group (8, 16 or 32).  A wave covers G = 32/S groups of one head.
-template <int S, int HD, bool BWD>
-__global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                               float* __restrict__ out, float* __restrict__ lse,
-                                                               float* __restrict__ dqkv, int64_t nb, int H, float scale) {
+template <int S, int HD, bool BWD, typename TIO>
+__global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __restrict__ qkv, const TIO* __restrict__ dout,
+                                                               TIO* __restrict__ out, float* __restrict__ lse,
+                                                               TIO* __restrict__ dqkv, int64_t nb, int H, float scale) {
     constexpr int G = 32 / S;
     using TL = Tile<HD>;
     constexpr int TRN = 2 * 32 * 33;  // P and dS transposes (backward), stride 33
@@ -119,13 +143,13 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __
     // Loads never branch on validity (a divergent branch around a load serialises load -> wait ->
     // MFMA): rows of groups past the end read group b0's row instead and are zeroed by a select.
     auto in_row = [&](int which) {
-        return [=](int r, bool& valid) -> const float* {
+        return [=](int r, bool& valid) -> const TIO* {
             const int64_t b = b0 + r / S;
             valid = b < nb;
             return qkv + GaPtrs<HD>::qkv(S, H, valid ? b : b0, r % S, which, head);
         };
     };
-    auto do_row = [=](int r, bool& valid) -> const float* {
+    auto do_row = [=](int r, bool& valid) -> const TIO* {
         const int64_t b = b0 + r / S;
         valid = b < nb;
         return dout + GaPtrs<HD>::o(S, H, valid ? b : b0, r % S, head);
@@ -180,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __
         const int j = acc_row(t, h2);
         const int64_t bj = b0 + j / S;
         const bool valid = bj < nb;
-        const float v = qkv[GaPtrs<HD>::qkv(S, H, valid ? bj : b0, j % S, which, head) + col];
+        const float v = load1(qkv + GaPtrs<HD>::qkv(S, H, valid ? bj : b0, j % S, which, head) + col);
         return valid ? v : 0.f;
     };
 
@@ -197,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __
             }
             TL::from_acc(lds, O, dblk, lane);
         }
-        TL::store(lds, [=](int r) -> float* {
+        TL::store(lds, [=](int r) -> TIO* {
             const int64_t b = b0 + r / S;
             return (b < nb) ? out + GaPtrs<HD>::o(S, H, b, r % S, head) : nullptr;
         }, lane);
@@ -243,11 +267,11 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __
             const int i = acc_row(t, h2);
             const int64_t bi = b0 + i / S;
             const bool valid = bi < nb;
-            const float v = dout[GaPtrs<HD>::o(S, H, valid ? bi : b0, i % S, head) + col];
+            const float v = load1(dout + GaPtrs<HD>::o(S, H, valid ? bi : b0, i % S, head) + col);
             return valid ? v : 0.f;
         };
         auto out_row = [&](int which) {
-            return [=](int r) -> float* {
+            return [=](int r) -> TIO* {
                 const int64_t b = b0 + r / S;
                 return (b < nb) ? dqkv + GaPtrs<HD>::qkv(S, H, b, r % S, which, head) : nullptr;
             };
@@ -294,16 +318,16 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const float* __
     }
 }
 
-template <bool BWD>
-static int launch_group_attention(const float* qkv, const float* dout, float* out, float* lse, float* dqkv,
+template <bool BWD, typename TIO>
+static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, float* lse, TIO* dqkv,
                                   int64_t nb, int s, int h, int hd, hipStream_t stream, const char* what) {
     PDA_REQUIRE(nb >= 0 && h >= 1, "%s: bad size", what);
     if (nb == 0) return PDA_OK;
     PDA_REQUIRE(qkv && lse && (BWD ? (dout && dqkv) : (out != nullptr)), "%s: null pointer", what);
     const int G = 32 / (s > 0 ? s : 1);
     const float scale = 1.0f / sqrtf((float)hd);
-    void (*kern)(const float*, const float*, float*, float*, float*, int64_t, int, float) = nullptr;
-#define PDA_GA_CASE(SS, DD) if (s == SS && hd == DD) kern = group_attention_kernel<SS, DD, BWD>
+    void (*kern)(const TIO*, const TIO*, TIO*, float*, TIO*, int64_t, int, float) = nullptr;
+#define PDA_GA_CASE(SS, DD) if (s == SS && hd == DD) kern = group_attention_kernel<SS, DD, BWD, TIO>
     PDA_GA_CASE(32, 64); PDA_GA_CASE(16, 64); PDA_GA_CASE(8, 64);
     PDA_GA_CASE(32, 128); PDA_GA_CASE(16, 128); PDA_GA_CASE(8, 128);
     PDA_GA_CASE(32, 32); PDA_GA_CASE(16, 32); PDA_GA_CASE(8, 32);
@@ -323,12 +347,24 @@ static int launch_group_attention(const float* qkv, const float* dout, float* ou
 
 PDA_API int pda_group_attention_fwd(const float* qkv, float* out, float* lse, int64_t num_groups, int seq,
                                     int heads, int head_dim, pda_stream_t stream) {
-    return pda::launch_group_attention<false>(qkv, nullptr, out, lse, nullptr, num_groups, seq, heads, head_dim,
+    return pda::launch_group_attention<false, float>(qkv, nullptr, out, lse, nullptr, num_groups, seq, heads, head_dim,
                                               (hipStream_t)stream, "pda_group_attention_fwd");
 }
 
 PDA_API int pda_group_attention_bwd(const float* qkv, const float* grad_out, const float* lse, float* grad_qkv,
                                     int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream) {
-    return pda::launch_group_attention<true>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups,
+    return pda::launch_group_attention<true, float>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups,
                                              seq, heads, head_dim, (hipStream_t)stream, "pda_group_attention_bwd");
+}
+
+PDA_API int pda_group_attention_fwd_bf16(const uint16_t* qkv, uint16_t* out, float* lse, int64_t num_groups, int seq,
+                                         int heads, int head_dim, pda_stream_t stream) {
+    return pda::launch_group_attention<false, pda::bf16_t>(qkv, nullptr, out, lse, nullptr, num_groups, seq, heads, head_dim,
+                                                           (hipStream_t)stream, "pda_group_attention_fwd_bf16");
+}
+
+PDA_API int pda_group_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* grad_out, const float* lse, uint16_t* grad_qkv,
+                                         int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream) {
+    return pda::launch_group_attention<true, pda::bf16_t>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups,
+                                                          seq, heads, head_dim, (hipStream_t)stream, "pda_group_attention_bwd_bf16");
 }

@@ -186,10 +186,12 @@ def chamfer_backward(xyz1, xyz2, gradxyz1, gradxyz2, graddist1, graddist2, idx1,
 
 
 def group_attention_fwd(qkv, out, lse, num_groups, seq, heads, head_dim):
-    """MI355X extension: attention over the tokens of each group (csrc/group_attention.hip)."""
+    """MI355X extension: attention over the tokens of each group (csrc/group_attention.hip).  qkv / out are fp32, or
+    both bf16 (dense-bf16 mode: the tensors next to the bf16 GEMMs); lse is always fp32."""
     _numel_ok(qkv, num_groups * seq * 3 * heads * head_dim, "qkv")
     _numel_ok(out, num_groups * seq * heads * head_dim, "out"); _numel_ok(lse, num_groups * heads * seq, "lse")
-    _call("pda_group_attention_fwd", qkv, _chk(qkv, "qkv", F32), _chk(out, "out", F32), _chk(lse, "lse", F32),
+    io, sfx = (torch.bfloat16, "_bf16") if qkv.dtype == torch.bfloat16 else (F32, "")
+    _call("pda_group_attention_fwd" + sfx, qkv, _chk(qkv, "qkv", io), _chk(out, "out", io), _chk(lse, "lse", F32),
           num_groups, seq, heads, head_dim)
     return 1
 
@@ -197,8 +199,9 @@ def group_attention_fwd(qkv, out, lse, num_groups, seq, heads, head_dim):
 def group_attention_bwd(qkv, grad_out, lse, grad_qkv, num_groups, seq, heads, head_dim):
     _numel_ok(qkv, num_groups * seq * 3 * heads * head_dim, "qkv"); _numel_ok(grad_qkv, qkv.numel(), "grad_qkv")
     _numel_ok(grad_out, num_groups * seq * heads * head_dim, "grad_out"); _numel_ok(lse, num_groups * heads * seq, "lse")
-    _call("pda_group_attention_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32),
-          _chk(lse, "lse", F32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
+    io, sfx = (torch.bfloat16, "_bf16") if qkv.dtype == torch.bfloat16 else (F32, "")
+    _call("pda_group_attention_bwd" + sfx, qkv, _chk(qkv, "qkv", io), _chk(grad_out, "grad_out", io),
+          _chk(lse, "lse", F32), _chk(grad_qkv, "grad_qkv", io), num_groups, seq, heads, head_dim)
     return 1
 
 

@@ -455,6 +455,7 @@ class LinearLongTokens(Function):
 DENSE_BF16 = False
 BF16_MIN_TOKENS = 32768     # below this (and for narrow layers) the operand casts cost more than the GEMM saves
 BF16_MIN_FEATURES = 128
+BF16_ATTENTION_IO = True    # dense-bf16 mode: qkv / attention output / their gradients live in HBM as bf16
 
 
 def _dense_bf16(x, weight=None):
@@ -595,8 +596,12 @@ class TransformerBlock(Function):
         src1 = torch.empty_like(x)
         st1 = torch.empty((T, 2), dtype=torch.float32, device=dev)
         pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
-        qkv, src1_s = lin(src1, in_w, in_b)
-        a = torch.empty((G, S, D), dtype=torch.float32, device=dev)
+        if bf16 and BF16_ATTENTION_IO:   # qkv and the attention output touch only GEMMs and the attention kernel: bf16 in HBM, bias in the epilogue
+            src1_s = _b16(src1.view(T, D))
+            qkv = torch.addmm(_b16(in_b), src1_s, _b16(in_w).t())
+        else:
+            qkv, src1_s = lin(src1, in_w, in_b)
+        a = torch.empty((G, S, D), dtype=qkv.dtype, device=dev)
         lse = torch.empty((G, heads, S), dtype=torch.float32, device=dev)
         pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
         proj, a_s = lin(a, out_w, out_b)
@@ -659,7 +664,7 @@ class TransformerBlock(Function):
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1)
         del d_lin1
         ds_g = op(d_s)
-        d_a = _mm_nn(ds_g, out_w, bf16)
+        d_a = (torch.mm(ds_g, _b16(out_w)) if qkv.dtype == torch.bfloat16 else _mm_nn(ds_g, out_w, True)) if bf16 else d_s.mm(out_w)
         gwo, gbo = _wgrad(a_s, ds_g, out_w, True, bf16)
         del ds_g
         dqkv = torch.empty_like(qkv)

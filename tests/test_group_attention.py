@@ -62,3 +62,32 @@ def test_transformer_layer_matches_sdpa_path():
     pm.GROUP_ATTENTION_KERNEL = True
     assert torch.allclose(outs[0], outs[1], atol=2e-5, rtol=1e-5)
     assert torch.allclose(grads[0], grads[1], atol=1e-8 + 1e-4 * grads[1].abs().max().item())
+
+
+@pytest.mark.parametrize("S,hd,G,heads", [(16, 64, 1027, 4), (32, 128, 77, 4), (8, 32, 5, 3), (32, 64, 1, 1)])
+def test_bf16_boundary_variant(S, hd, G, heads):
+    """pda_group_attention_{fwd,bwd}_bf16: same arithmetic, bf16 tensors at the HBM boundary.  On inputs that ARE
+    bf16 values the results must equal the fp32 kernels' results rounded once to bf16 (1 ulp = 2^-8 relative slack for
+    results that sit on a rounding boundary and differ in the last fp32 bits)."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(S + hd + G)
+    D = heads * hd
+    qkv_b = (torch.randn(G, S, 3 * D, device="cuda") * 0.7).bfloat16()
+    go_b = torch.randn(G, S, D, device="cuda").bfloat16()
+    qkv, go = qkv_b.float(), go_b.float()
+    out, lse = torch.empty(G, S, D, device="cuda"), torch.empty(G, heads, S, device="cuda")
+    ext.group_attention_fwd(qkv, out, lse, G, S, heads, hd)
+    dqkv = torch.empty_like(qkv)
+    ext.group_attention_bwd(qkv, go, lse, dqkv, G, S, heads, hd)
+    out_b, lse_b = torch.empty(G, S, D, device="cuda", dtype=torch.bfloat16), torch.empty_like(lse)
+    ext.group_attention_fwd(qkv_b, out_b, lse_b, G, S, heads, hd)
+    dqkv_b = torch.empty_like(qkv_b)
+    ext.group_attention_bwd(qkv_b, go_b, lse_b, dqkv_b, G, S, heads, hd)
+    assert torch.equal(lse, lse_b)
+    for got, want in ((out_b, out), (dqkv_b, dqkv)):
+        assert got.dtype == torch.bfloat16
+        exact = (got == want.bfloat16()).float().mean().item()
+        assert exact > 0.999, exact
+        assert (got.float() - want).abs().max().item() <= 2.0 ** -8 * want.abs().max().item()
+    with pytest.raises(RuntimeError):
+        ext.group_attention_fwd(qkv_b, out, lse, G, S, heads, hd)   # mixed dtypes are refused
