@@ -59,6 +59,16 @@ int pda_layer_norm_fwd(const float *x, const float *residual, const float *gamma
 int pda_layer_norm_bwd(const float *x, const float *grad_y, const float *grad_y2, const float *gamma,
                        const float *mean_rstd, float *grad_x, float *grad_gamma, float *grad_beta,
                        void *scratch, int64_t rows, int d, pda_stream_t stream);
+/* Dense-bf16 mode variants (same kernels, same fp32 arithmetic; bf16 = raw bit patterns, rounded to nearest even on the
+ * store): x may be the bf16 output of a GEMM (x_is_bf16), y (fp32) and y_bf16 (a copy for the next bf16 GEMM) are each
+ * optional (at least one); grad_y2 may be bf16; grad_x_bf16 (may be NULL) receives a bf16 copy of grad_x. */
+int pda_layer_norm_fwd_mixed(const void *x, int x_is_bf16, const float *residual, const float *gamma,
+                             const float *beta, float *sum_out, float *y, uint16_t *y_bf16, float *mean_rstd,
+                             int64_t rows, int d, float eps, pda_stream_t stream);
+int pda_layer_norm_bwd_mixed(const float *x, const float *grad_y, const void *grad_y2, int grad_y2_is_bf16,
+                             const float *gamma, const float *mean_rstd, float *grad_x, uint16_t *grad_x_bf16,
+                             float *grad_gamma, float *grad_beta, void *scratch, int64_t rows, int d,
+                             pda_stream_t stream);
 
 /* ---- weight / bias gradient of a linear layer over a long token axis (MI355X extension) -------------
  * The backward GEMMs of the point-major 1x1 convolutions and transformer projections: x (tokens, in),
@@ -90,6 +100,11 @@ int pda_add_max_pool(const float *a, const float *b, float *out, uint8_t *arg, i
                      pda_stream_t stream);
 int pda_max_pool_scatter(const float *grad_out, const uint8_t *arg, float *grad_x, int64_t groups, int seq,
                          int d, pda_stream_t stream);
+/* Dense-bf16 mode: b is the bf16 output of a GEMM; the scatter also writes a bf16 copy of the gradient. */
+int pda_add_max_pool_bf16(const float *a, const uint16_t *b, float *out, uint8_t *arg, int64_t groups, int seq,
+                          int d, pda_stream_t stream);
+int pda_max_pool_scatter_bf16(const float *grad_out, const uint8_t *arg, float *grad_x, uint16_t *grad_x_bf16,
+                              int64_t groups, int seq, int d, pda_stream_t stream);
 
 /* ---- DensityNet in training mode (MI355X extension) ----------------------------------------------
  * pointnet2_modules.py:958-981: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) with 1x1 convs

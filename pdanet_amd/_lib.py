@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -50,12 +50,16 @@ SIGNATURES = {
     "pda_layer_norm_scratch_bytes": [_i],
     "pda_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],
     "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
+    "pda_layer_norm_fwd_mixed": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],
+    "pda_layer_norm_bwd_mixed": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_assemble_tokens_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_add_max_pool": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_max_pool_scatter": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_add_max_pool_bf16": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_max_pool_scatter_bf16": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_densitynet_param_count": [],
     "pda_densitynet_scratch_bytes": [],
     "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],

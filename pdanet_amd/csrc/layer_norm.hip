@@ -18,12 +18,14 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-// V = float4 chunks per lane: D = 256 * V
-template <int V, bool RESIDUAL>
-__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ res,
+// V = float4 chunks per lane: D = 256 * V.  TX: element type of x (float, or bf16 when x comes out of a bf16 GEMM);
+// y (fp32) and yb (a bf16 copy for the next bf16 GEMM) are each optional.
+template <int V, bool RESIDUAL, typename TX>
+__global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ res,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ sum_out, float* __restrict__ y,
-                                                             float* __restrict__ mean_rstd, int64_t rows, float eps) {
+                                                             bf16_t* __restrict__ yb, float* __restrict__ mean_rstd, int64_t rows,
+                                                             float eps) {
     constexpr int D = 256 * V;
     const int lane = lane_id();
     float4 g[V], be[V];
@@ -37,7 +39,7 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
         float s = 0.f;
 #pragma unroll
         for (int v = 0; v < V; ++v) {
-            a[v] = reinterpret_cast<const float4*>(x + r * D)[v * 64 + lane];
+            a[v] = load4(x + r * D + 4 * (v * 64 + lane));
             if (RESIDUAL) {
                 const float4 b = reinterpret_cast<const float4*>(res + r * D)[v * 64 + lane];
                 a[v].x += b.x; a[v].y += b.y; a[v].z += b.z; a[v].w += b.w;
@@ -60,18 +62,20 @@ __global__ __launch_bounds__(256) void layer_norm_fwd_kernel(const float* __rest
             o.y = (a[v].y - mean) * rstd * g[v].y + be[v].y;
             o.z = (a[v].z - mean) * rstd * g[v].z + be[v].z;
             o.w = (a[v].w - mean) * rstd * g[v].w + be[v].w;
-            reinterpret_cast<float4*>(y + r * D)[v * 64 + lane] = o;
+            if (y) reinterpret_cast<float4*>(y + r * D)[v * 64 + lane] = o;
+            if (yb) store4(yb + r * D + 4 * (v * 64 + lane), o);
         }
         if (lane == 0) { mean_rstd[r * 2] = mean; mean_rstd[r * 2 + 1] = rstd; }
     }
 }
 
 // TWO: the incoming gradient is dy + dy2 (a residual branch and a projection's input gradient), added on the fly
-template <int V, bool TWO>
+// (T2: element type of dy2; dxb: optional bf16 copy of dx for the bf16 GEMMs that consume it)
+template <int V, bool TWO, typename T2>
 __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
-                                                             const float* __restrict__ dy2, const float* __restrict__ gamma,
+                                                             const T2* __restrict__ dy2, const float* __restrict__ gamma,
                                                              const float* __restrict__ mean_rstd, float* __restrict__ dx,
-                                                             float* __restrict__ partial, int64_t rows) {
+                                                             bf16_t* __restrict__ dxb, float* __restrict__ partial, int64_t rows) {
     constexpr int D = 256 * V;
     __shared__ float red[2][4][D];
     const int lane = lane_id(), w = wave_id();
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __rest
             const float4 xv = reinterpret_cast<const float4*>(x + r * D)[v * 64 + lane];
             d[v] = reinterpret_cast<const float4*>(dy + r * D)[v * 64 + lane];
             if (TWO) {
-                const float4 e = reinterpret_cast<const float4*>(dy2 + r * D)[v * 64 + lane];
+                const float4 e = load4(dy2 + r * D + 4 * (v * 64 + lane));
                 d[v].x += e.x; d[v].y += e.y; d[v].z += e.z; d[v].w += e.w;
             }
             xh[v] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* __rest
             o.z = rstd * (d[v].z - m1 - xh[v].z * m2);
             o.w = rstd * (d[v].w - m1 - xh[v].w * m2);
             reinterpret_cast<float4*>(dx + r * D)[v * 64 + lane] = o;
+            if (dxb) store4(dxb + r * D + 4 * (v * 64 + lane), o);
         }
     }
 #pragma unroll
@@ -162,44 +167,84 @@ static int ln_grid(int64_t rows) {
 
 PDA_API int64_t pda_layer_norm_scratch_bytes(int d) { return (int64_t)pda::LN_BLOCKS * 2 * (d > 0 ? d : 0) * (int64_t)sizeof(float); }
 
-PDA_API int pda_layer_norm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* sum_out,
-                               float* y, float* mean_rstd, int64_t rows, int d, float eps, pda_stream_t stream) {
-    PDA_REQUIRE(rows >= 0, "pda_layer_norm_fwd: rows = %lld", (long long)rows);
-    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "pda_layer_norm_fwd: D = %d (256, 512 or 1024)", d);
+namespace pda {
+
+template <typename TX>
+static int launch_layer_norm_fwd(const TX* x, const float* residual, const float* gamma, const float* beta, float* sum_out, float* y,
+                                 bf16_t* yb, float* mean_rstd, int64_t rows, int d, float eps, hipStream_t st, const char* what) {
+    PDA_REQUIRE(rows >= 0, "%s: rows = %lld", what, (long long)rows);
+    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "%s: D = %d (256, 512 or 1024)", what, d);
     if (rows == 0) return PDA_OK;
-    PDA_REQUIRE(x && gamma && beta && y && mean_rstd, "pda_layer_norm_fwd: null pointer");
-    PDA_REQUIRE((residual == nullptr) == (sum_out == nullptr), "pda_layer_norm_fwd: residual and sum_out come together");
-    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual | (uintptr_t)sum_out) & 15) == 0,
-                "pda_layer_norm_fwd: pointers must be 16-byte aligned");
-    const dim3 grid(pda::ln_grid(rows)), block(256);
-    hipStream_t st = (hipStream_t)stream;
+    PDA_REQUIRE(x && gamma && beta && (y || yb) && mean_rstd, "%s: null pointer", what);
+    PDA_REQUIRE((residual == nullptr) == (sum_out == nullptr), "%s: residual and sum_out come together", what);
+    PDA_REQUIRE((((uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)residual | (uintptr_t)sum_out) & 15) == 0 &&
+                    (((uintptr_t)x | (uintptr_t)yb) & (4 * sizeof(TX) - 1) & 15) == 0 && ((uintptr_t)yb & 7) == 0,
+                "%s: pointers must be 16-byte aligned (8 for bf16 tensors)", what);
+    const dim3 grid(ln_grid(rows)), block(256);
 #define PDA_LN_FWD(V)                                                                                                          \
-    if (residual) hipLaunchKernelGGL((pda::layer_norm_fwd_kernel<V, true>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, mean_rstd, rows, eps); \
-    else hipLaunchKernelGGL((pda::layer_norm_fwd_kernel<V, false>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, mean_rstd, rows, eps)
+    if (residual) hipLaunchKernelGGL((layer_norm_fwd_kernel<V, true, TX>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, yb, mean_rstd, rows, eps); \
+    else hipLaunchKernelGGL((layer_norm_fwd_kernel<V, false, TX>), grid, block, 0, st, x, residual, gamma, beta, sum_out, y, yb, mean_rstd, rows, eps)
     if (d == 256) { PDA_LN_FWD(1); } else if (d == 512) { PDA_LN_FWD(2); } else { PDA_LN_FWD(4); }
 #undef PDA_LN_FWD
-    return pda::check_launch("pda_layer_norm_fwd");
+    return check_launch(what);
+}
+
+template <typename T2>
+static int launch_layer_norm_bwd(const float* x, const float* grad_y, const T2* grad_y2, const float* gamma, const float* mean_rstd,
+                                 float* grad_x, bf16_t* grad_x_b, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int d,
+                                 hipStream_t st, const char* what) {
+    PDA_REQUIRE(rows >= 1, "%s: rows = %lld", what, (long long)rows);
+    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "%s: D = %d (256, 512 or 1024)", what, d);
+    PDA_REQUIRE(x && grad_y && gamma && mean_rstd && grad_x && grad_gamma && grad_beta && scratch, "%s: null pointer", what);
+    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)gamma) & 15) == 0 &&
+                    ((uintptr_t)grad_y2 & (4 * sizeof(T2) - 1)) == 0 && ((uintptr_t)grad_x_b & 7) == 0,
+                "%s: pointers must be 16-byte aligned (8 for bf16 tensors)", what);
+    const int nblocks = ln_grid(rows);
+    const dim3 grid(nblocks), block(256);
+    float* partial = (float*)scratch;
+#define PDA_LN_BWD(V)                                                                                                               \
+    if (grad_y2) hipLaunchKernelGGL((layer_norm_bwd_kernel<V, true, T2>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, grad_x_b, partial, rows); \
+    else hipLaunchKernelGGL((layer_norm_bwd_kernel<V, false, T2>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, grad_x_b, partial, rows)
+    if (d == 256) { PDA_LN_BWD(1); } else if (d == 512) { PDA_LN_BWD(2); } else { PDA_LN_BWD(4); }
+#undef PDA_LN_BWD
+    hipLaunchKernelGGL(layer_norm_finalize_kernel, dim3(divup(d, 64)), dim3(1024), 0, st, partial, nblocks, d, grad_gamma, grad_beta);
+    return check_launch(what);
+}
+
+}  // namespace pda
+
+PDA_API int pda_layer_norm_fwd(const float* x, const float* residual, const float* gamma, const float* beta, float* sum_out,
+                               float* y, float* mean_rstd, int64_t rows, int d, float eps, pda_stream_t stream) {
+    PDA_REQUIRE(y != nullptr || rows == 0, "pda_layer_norm_fwd: null pointer");
+    return pda::launch_layer_norm_fwd<float>(x, residual, gamma, beta, sum_out, y, nullptr, mean_rstd, rows, d, eps, (hipStream_t)stream,
+                                             "pda_layer_norm_fwd");
+}
+
+PDA_API int pda_layer_norm_fwd_mixed(const void* x, int x_is_bf16, const float* residual, const float* gamma, const float* beta,
+                                     float* sum_out, float* y, uint16_t* y_bf16, float* mean_rstd, int64_t rows, int d, float eps,
+                                     pda_stream_t stream) {
+    if (x_is_bf16)
+        return pda::launch_layer_norm_fwd<pda::bf16_t>((const pda::bf16_t*)x, residual, gamma, beta, sum_out, y, y_bf16, mean_rstd, rows, d,
+                                                       eps, (hipStream_t)stream, "pda_layer_norm_fwd_mixed");
+    return pda::launch_layer_norm_fwd<float>((const float*)x, residual, gamma, beta, sum_out, y, y_bf16, mean_rstd, rows, d, eps,
+                                             (hipStream_t)stream, "pda_layer_norm_fwd_mixed");
 }
 
 PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float* grad_y2, const float* gamma, const float* mean_rstd,
                                float* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int d,
                                pda_stream_t stream) {
-    PDA_REQUIRE(rows >= 1, "pda_layer_norm_bwd: rows = %lld", (long long)rows);
-    PDA_REQUIRE(d == 256 || d == 512 || d == 1024, "pda_layer_norm_bwd: D = %d (256, 512 or 1024)", d);
-    PDA_REQUIRE(x && grad_y && gamma && mean_rstd && grad_x && grad_gamma && grad_beta && scratch, "pda_layer_norm_bwd: null pointer");
-    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_y2 | (uintptr_t)grad_x | (uintptr_t)gamma) & 15) == 0,
-                "pda_layer_norm_bwd: pointers must be 16-byte aligned");
-    const int nblocks = pda::ln_grid(rows);
-    const dim3 grid(nblocks), block(256);
-    hipStream_t st = (hipStream_t)stream;
-    float* partial = (float*)scratch;
-#define PDA_LN_BWD(V)                                                                                                               \
-    if (grad_y2) hipLaunchKernelGGL((pda::layer_norm_bwd_kernel<V, true>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, partial, rows); \
-    else hipLaunchKernelGGL((pda::layer_norm_bwd_kernel<V, false>), grid, block, 0, st, x, grad_y, grad_y2, gamma, mean_rstd, grad_x, partial, rows)
-    if (d == 256) { PDA_LN_BWD(1); } else if (d == 512) { PDA_LN_BWD(2); } else { PDA_LN_BWD(4); }
-#undef PDA_LN_BWD
-    hipLaunchKernelGGL(pda::layer_norm_finalize_kernel, dim3(pda::divup(d, 64)), dim3(1024), 0, st, partial, nblocks, d, grad_gamma, grad_beta);
-    return pda::check_launch("pda_layer_norm_bwd");
+    return pda::launch_layer_norm_bwd<float>(x, grad_y, grad_y2, gamma, mean_rstd, grad_x, nullptr, grad_gamma, grad_beta, scratch, rows, d,
+                                             (hipStream_t)stream, "pda_layer_norm_bwd");
+}
+
+PDA_API int pda_layer_norm_bwd_mixed(const float* x, const float* grad_y, const void* grad_y2, int grad_y2_is_bf16, const float* gamma,
+                                     const float* mean_rstd, float* grad_x, uint16_t* grad_x_bf16, float* grad_gamma, float* grad_beta,
+                                     void* scratch, int64_t rows, int d, pda_stream_t stream) {
+    if (grad_y2_is_bf16)
+        return pda::launch_layer_norm_bwd<pda::bf16_t>(x, grad_y, (const pda::bf16_t*)grad_y2, gamma, mean_rstd, grad_x, grad_x_bf16,
+                                                       grad_gamma, grad_beta, scratch, rows, d, (hipStream_t)stream, "pda_layer_norm_bwd_mixed");
+    return pda::launch_layer_norm_bwd<float>(x, grad_y, (const float*)grad_y2, gamma, mean_rstd, grad_x, grad_x_bf16, grad_gamma, grad_beta,
+                                             scratch, rows, d, (hipStream_t)stream, "pda_layer_norm_bwd_mixed");
 }
 
 // ---- residual add + max-pool over the tokens of a group -------------------------------------------------
@@ -208,7 +253,8 @@ PDA_API int pda_layer_norm_bwd(const float* x, const float* grad_y, const float*
 // for the backward pass, which writes the dense (G, S, D) gradient in one pass (zeros + the routed values).
 namespace pda {
 
-__global__ __launch_bounds__(256) void add_max_pool_kernel(const float* __restrict__ a, const float* __restrict__ b,
+template <typename TB>
+__global__ __launch_bounds__(256) void add_max_pool_kernel(const float* __restrict__ a, const TB* __restrict__ b,
                                                            float* __restrict__ out, uint8_t* __restrict__ arg, int64_t groups,
                                                            int s, int d4) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (group, 4-channel column)
@@ -216,11 +262,11 @@ __global__ __launch_bounds__(256) void add_max_pool_kernel(const float* __restri
     const int64_t g = e / d4;
     const int c = (int)(e % d4);
     const float4* pa = reinterpret_cast<const float4*>(a) + (size_t)g * s * d4 + c;
-    const float4* pb = reinterpret_cast<const float4*>(b) + (size_t)g * s * d4 + c;
+    const TB* pb = b + 4 * ((size_t)g * s * d4 + c);
     float4 best = make_float4(-__builtin_inff(), -__builtin_inff(), -__builtin_inff(), -__builtin_inff());
     uchar4 bi = make_uchar4(0, 0, 0, 0);
     for (int t = 0; t < s; ++t) {
-        const float4 x = pa[(size_t)t * d4], y = pb[(size_t)t * d4];
+        const float4 x = pa[(size_t)t * d4], y = load4(pb + 4 * (size_t)t * d4);
         const float4 v = make_float4(x.x + y.x, x.y + y.y, x.z + y.z, x.w + y.w);
         if (v.x > best.x) { best.x = v.x; bi.x = (uint8_t)t; }
         if (v.y > best.y) { best.y = v.y; bi.y = (uint8_t)t; }
@@ -232,7 +278,8 @@ __global__ __launch_bounds__(256) void add_max_pool_kernel(const float* __restri
 }
 
 __global__ __launch_bounds__(256) void max_pool_scatter_kernel(const float* __restrict__ dout, const uint8_t* __restrict__ arg,
-                                                               float* __restrict__ dx, int64_t groups, int s, int d4) {
+                                                               float* __restrict__ dx, bf16_t* __restrict__ dxb, int64_t groups, int s,
+                                                               int d4) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;      // (group, token, 4-channel column)
     if (e >= groups * s * d4) return;
     const int c = (int)(e % d4);
@@ -240,33 +287,60 @@ __global__ __launch_bounds__(256) void max_pool_scatter_kernel(const float* __re
     const int64_t g = e / ((int64_t)d4 * s);
     const float4 v = reinterpret_cast<const float4*>(dout)[g * d4 + c];
     const uchar4 k = reinterpret_cast<const uchar4*>(arg)[g * d4 + c];
-    reinterpret_cast<float4*>(dx)[e] = make_float4(k.x == t ? v.x : 0.f, k.y == t ? v.y : 0.f, k.z == t ? v.z : 0.f, k.w == t ? v.w : 0.f);
+    const float4 o = make_float4(k.x == t ? v.x : 0.f, k.y == t ? v.y : 0.f, k.z == t ? v.z : 0.f, k.w == t ? v.w : 0.f);
+    reinterpret_cast<float4*>(dx)[e] = o;
+    if (dxb) store4(dxb + 4 * e, o);
+}
+
+}  // namespace pda
+
+namespace pda {
+
+template <typename TB>
+static int launch_add_max_pool(const float* a, const TB* b, float* out, uint8_t* arg, int64_t groups, int seq, int d, hipStream_t st,
+                               const char* what) {
+    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "%s: groups=%lld seq=%d d=%d", what, (long long)groups, seq, d);
+    if (groups == 0) return PDA_OK;
+    PDA_REQUIRE(a && b && out && arg, "%s: null pointer", what);
+    PDA_REQUIRE((((uintptr_t)a | (uintptr_t)out) & 15) == 0 && ((uintptr_t)b & (4 * sizeof(TB) - 1)) == 0 && ((uintptr_t)arg & 3) == 0,
+                "%s: alignment", what);
+    const int64_t n = groups * (d / 4);
+    hipLaunchKernelGGL(add_max_pool_kernel<TB>, dim3((unsigned)divup64(n, 256)), dim3(256), 0, st, a, b, out, arg, groups, seq, d / 4);
+    return check_launch(what);
+}
+
+static int launch_max_pool_scatter(const float* grad_out, const uint8_t* arg, float* grad_x, bf16_t* grad_x_b, int64_t groups, int seq, int d,
+                                   hipStream_t st, const char* what) {
+    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "%s: groups=%lld seq=%d d=%d", what, (long long)groups, seq, d);
+    if (groups == 0) return PDA_OK;
+    PDA_REQUIRE(grad_out && arg && grad_x, "%s: null pointer", what);
+    PDA_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_x) & 15) == 0 && ((uintptr_t)arg & 3) == 0 && ((uintptr_t)grad_x_b & 7) == 0,
+                "%s: alignment", what);
+    const int64_t n = groups * seq * (d / 4);
+    hipLaunchKernelGGL(max_pool_scatter_kernel, dim3((unsigned)divup64(n, 256)), dim3(256), 0, st, grad_out, arg, grad_x, grad_x_b, groups,
+                       seq, d / 4);
+    return check_launch(what);
 }
 
 }  // namespace pda
 
 PDA_API int pda_add_max_pool(const float* a, const float* b, float* out, uint8_t* arg, int64_t groups, int seq, int d,
                              pda_stream_t stream) {
-    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "pda_add_max_pool: groups=%lld seq=%d d=%d",
-                (long long)groups, seq, d);
-    if (groups == 0) return PDA_OK;
-    PDA_REQUIRE(a && b && out && arg, "pda_add_max_pool: null pointer");
-    PDA_REQUIRE((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0 && ((uintptr_t)arg & 3) == 0, "pda_add_max_pool: alignment");
-    const int64_t n = groups * (d / 4);
-    hipLaunchKernelGGL(pda::add_max_pool_kernel, dim3((unsigned)pda::divup64(n, 256)), dim3(256), 0, (hipStream_t)stream, a, b, out, arg,
-                       groups, seq, d / 4);
-    return pda::check_launch("pda_add_max_pool");
+    return pda::launch_add_max_pool<float>(a, b, out, arg, groups, seq, d, (hipStream_t)stream, "pda_add_max_pool");
+}
+
+PDA_API int pda_add_max_pool_bf16(const float* a, const uint16_t* b, float* out, uint8_t* arg, int64_t groups, int seq, int d,
+                                  pda_stream_t stream) {
+    return pda::launch_add_max_pool<pda::bf16_t>(a, b, out, arg, groups, seq, d, (hipStream_t)stream, "pda_add_max_pool_bf16");
 }
 
 PDA_API int pda_max_pool_scatter(const float* grad_out, const uint8_t* arg, float* grad_x, int64_t groups, int seq, int d,
                                  pda_stream_t stream) {
-    PDA_REQUIRE(groups >= 0 && seq >= 1 && seq <= 255 && d >= 4 && (d & 3) == 0, "pda_max_pool_scatter: groups=%lld seq=%d d=%d",
-                (long long)groups, seq, d);
-    if (groups == 0) return PDA_OK;
-    PDA_REQUIRE(grad_out && arg && grad_x, "pda_max_pool_scatter: null pointer");
-    PDA_REQUIRE((((uintptr_t)grad_out | (uintptr_t)grad_x) & 15) == 0 && ((uintptr_t)arg & 3) == 0, "pda_max_pool_scatter: alignment");
-    const int64_t n = groups * seq * (d / 4);
-    hipLaunchKernelGGL(pda::max_pool_scatter_kernel, dim3((unsigned)pda::divup64(n, 256)), dim3(256), 0, (hipStream_t)stream, grad_out,
-                       arg, grad_x, groups, seq, d / 4);
-    return pda::check_launch("pda_max_pool_scatter");
+    return pda::launch_max_pool_scatter(grad_out, arg, grad_x, nullptr, groups, seq, d, (hipStream_t)stream, "pda_max_pool_scatter");
+}
+
+PDA_API int pda_max_pool_scatter_bf16(const float* grad_out, const uint8_t* arg, float* grad_x, uint16_t* grad_x_bf16, int64_t groups,
+                                      int seq, int d, pda_stream_t stream) {
+    PDA_REQUIRE(grad_x_bf16 != nullptr || groups == 0, "pda_max_pool_scatter_bf16: null pointer");
+    return pda::launch_max_pool_scatter(grad_out, arg, grad_x, grad_x_bf16, groups, seq, d, (hipStream_t)stream, "pda_max_pool_scatter_bf16");
 }

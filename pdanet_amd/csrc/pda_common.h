@@ -57,6 +57,30 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 }
 
 // wave-uniform wave index inside the workgroup, provably uniform to the compiler
+// Tensor element type at the HBM boundary: float, or bf16 (raw uint16_t) in the dense-bf16 mode, where qkv / dout come
+// straight out of bf16 GEMMs and out / dqkv go straight into them.  All arithmetic is fp32 either way.
+typedef uint16_t bf16_t;
+__device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float((uint32_t)u << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
+    const uint32_t b = __float_as_uint(f);
+    return (f != f) ? (bf16_t)0x7fc0 : (bf16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+}
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
+    uint2 u;
+    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
+    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float load1(const float* p) { return *p; }
+__device__ __forceinline__ float load1(const bf16_t* p) { return bf16_to_f32(*p); }
+
 __device__ __forceinline__ int wave_id() {
     return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
 }

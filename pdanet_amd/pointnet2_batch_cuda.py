@@ -232,22 +232,46 @@ def layer_norm_scratch_bytes(d):
     return int(_lib.load().pda_layer_norm_scratch_bytes(int(d)))
 
 
-def layer_norm_fwd(x, residual, gamma, beta, sum_out, y, mean_rstd, rows, d, eps):
-    """MI355X extension: LayerNorm over the last dim with optional fused residual add (csrc/layer_norm.hip)."""
-    _numel_ok(x, rows * d, "x"); _numel_ok(y, rows * d, "y"); _numel_ok(mean_rstd, rows * 2, "mean_rstd")
+BF16 = torch.bfloat16
+
+
+def layer_norm_fwd(x, residual, gamma, beta, sum_out, y, mean_rstd, rows, d, eps, y_bf16=None):
+    """MI355X extension: LayerNorm over the last dim with optional fused residual add (csrc/layer_norm.hip).
+    Dense-bf16 mode: x may be bf16 (a GEMM output), y may be None when only the bf16 copy y_bf16 is wanted."""
+    _numel_ok(x, rows * d, "x"); _numel_ok(mean_rstd, rows * 2, "mean_rstd")
     res = None if residual is None else _chk(residual, "residual", F32)
     so = None if sum_out is None else _chk(sum_out, "sum_out", F32)
-    _call("pda_layer_norm_fwd", x, _chk(x, "x", F32), res, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), so,
-          _chk(y, "y", F32), _chk(mean_rstd, "mean_rstd", F32), rows, d, float(eps))
+    if x.dtype == F32 and y_bf16 is None:
+        _numel_ok(y, rows * d, "y")
+        _call("pda_layer_norm_fwd", x, _chk(x, "x", F32), res, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), so,
+              _chk(y, "y", F32), _chk(mean_rstd, "mean_rstd", F32), rows, d, float(eps))
+        return 1
+    yp = yb = None
+    if y is not None:
+        _numel_ok(y, rows * d, "y"); yp = _chk(y, "y", F32)
+    if y_bf16 is not None:
+        _numel_ok(y_bf16, rows * d, "y_bf16"); yb = _chk(y_bf16, "y_bf16", BF16)
+    _call("pda_layer_norm_fwd_mixed", x, _chk(x, "x", x.dtype if x.dtype == BF16 else F32), int(x.dtype == BF16), res,
+          _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), so, yp, yb, _chk(mean_rstd, "mean_rstd", F32), rows, d, float(eps))
     return 1
 
 
-def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, scratch, rows, d, grad_y2=None):
+def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, scratch, rows, d, grad_y2=None, grad_x_bf16=None):
+    """grad_y2: optional second incoming gradient (fp32, or bf16 in dense-bf16 mode); grad_x_bf16: optional bf16 copy of grad_x."""
     _numel_ok(x, rows * d, "x"); _numel_ok(grad_y, rows * d, "grad_y"); _numel_ok(grad_x, rows * d, "grad_x")
     g2 = None
     if grad_y2 is not None:
         _numel_ok(grad_y2, rows * d, "grad_y2")
-        g2 = _chk(grad_y2, "grad_y2", F32)
+        g2 = _chk(grad_y2, "grad_y2", BF16 if grad_y2.dtype == BF16 else F32)
+    if grad_x_bf16 is not None or (grad_y2 is not None and grad_y2.dtype == BF16):
+        gxb = None
+        if grad_x_bf16 is not None:
+            _numel_ok(grad_x_bf16, rows * d, "grad_x_bf16"); gxb = _chk(grad_x_bf16, "grad_x_bf16", BF16)
+        _call("pda_layer_norm_bwd_mixed", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), g2,
+              int(grad_y2 is not None and grad_y2.dtype == BF16), _chk(gamma, "gamma", F32), _chk(mean_rstd, "mean_rstd", F32),
+              _chk(grad_x, "grad_x", F32), gxb, _chk(grad_gamma, "grad_gamma", F32), _chk(grad_beta, "grad_beta", F32),
+              _chk(scratch, "scratch", torch.uint8), rows, d)
+        return 1
     _call("pda_layer_norm_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), g2, _chk(gamma, "gamma", F32),
           _chk(mean_rstd, "mean_rstd", F32), _chk(grad_x, "grad_x", F32), _chk(grad_gamma, "grad_gamma", F32),
           _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, d)
@@ -300,12 +324,18 @@ def pda_geometry(xyz, new_xyz, idx, rppe, dscale, b, n, m, nsample, radius):
 def add_max_pool(a, b, out, arg, groups, seq, d):
     """MI355X extension: out = max over the seq tokens of a + b, arg = first arg-max token (csrc/layer_norm.hip)."""
     _numel_ok(a, groups * seq * d, "a"); _numel_ok(b, groups * seq * d, "b"); _numel_ok(out, groups * d, "out"); _numel_ok(arg, groups * d, "arg")
-    _call("pda_add_max_pool", a, _chk(a, "a", F32), _chk(b, "b", F32), _chk(out, "out", F32), _chk(arg, "arg", torch.uint8), groups, seq, d)
+    io, sfx = (BF16, "_bf16") if b.dtype == BF16 else (F32, "")      # b: a GEMM output, bf16 in dense-bf16 mode
+    _call("pda_add_max_pool" + sfx, a, _chk(a, "a", F32), _chk(b, "b", io), _chk(out, "out", F32), _chk(arg, "arg", torch.uint8), groups, seq, d)
     return 1
 
 
-def max_pool_scatter(grad_out, arg, grad_x, groups, seq, d):
+def max_pool_scatter(grad_out, arg, grad_x, groups, seq, d, grad_x_bf16=None):
     _numel_ok(grad_out, groups * d, "grad_out"); _numel_ok(arg, groups * d, "arg"); _numel_ok(grad_x, groups * seq * d, "grad_x")
+    if grad_x_bf16 is not None:
+        _numel_ok(grad_x_bf16, groups * seq * d, "grad_x_bf16")
+        _call("pda_max_pool_scatter_bf16", grad_out, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8), _chk(grad_x, "grad_x", F32),
+              _chk(grad_x_bf16, "grad_x_bf16", BF16), groups, seq, d)
+        return 1
     _call("pda_max_pool_scatter", grad_out, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8), _chk(grad_x, "grad_x", F32),
           groups, seq, d)
     return 1

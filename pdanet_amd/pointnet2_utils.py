@@ -455,7 +455,6 @@ class LinearLongTokens(Function):
 DENSE_BF16 = False
 BF16_MIN_TOKENS = 32768     # below this (and for narrow layers) the operand casts cost more than the GEMM saves
 BF16_MIN_FEATURES = 128
-BF16_ATTENTION_IO = True    # dense-bf16 mode: qkv / attention output / their gradients live in HBM as bf16
 
 
 def _dense_bf16(x, weight=None):
@@ -588,37 +587,43 @@ class TransformerBlock(Function):
     @staticmethod
     def forward(ctx, x, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2, pool):
         bf16 = _dense_bf16(x)
-        lin = lambda t, w, b: _lin(t, w, b, bf16, keep=True)  # noqa: E731  (y, the GEMM's input operand as fed)
         x = x.contiguous()
         G, S, D = x.shape
         T, hd = G * S, D // heads
         dev = x.device
-        src1 = torch.empty_like(x)
-        st1 = torch.empty((T, 2), dtype=torch.float32, device=dev)
-        pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
-        if bf16 and BF16_ATTENTION_IO:   # qkv and the attention output touch only GEMMs and the attention kernel: bf16 in HBM, bias in the epilogue
-            src1_s = _b16(src1.view(T, D))
+        f32 = dict(dtype=torch.float32, device=dev)
+        src1, ssum, src2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        st1, st2 = torch.empty((T, 2), **f32), torch.empty((T, 2), **f32)
+        lse = torch.empty((G, heads, S), **f32)
+        if bf16:
+            # Dense-bf16 mode.  Every tensor that sits between a GEMM and one of this repo's kernels crosses HBM as
+            # bf16: the GEMMs write bf16 with bias (+ ReLU) in their epilogue, the kernels read bf16 / emit the bf16
+            # operand copy next to their fp32 output.  The residual stream (x, src1, ssum, src2), the statistics and
+            # all kernel arithmetic stay fp32.  No cast or bias pass remains.
+            b16 = dict(dtype=torch.bfloat16, device=dev)
+            src1_s, src2_s = torch.empty((T, D), **b16), torch.empty((T, D), **b16)
+            pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1, y_bf16=src1_s)
             qkv = torch.addmm(_b16(in_b), src1_s, _b16(in_w).t())
+            a_s = torch.empty((T, D), **b16)
+            pointnet2.group_attention_fwd(qkv, a_s, lse, G, S, heads, hd)
+            proj = torch.addmm(_b16(out_b), a_s, _b16(out_w).t())
+            pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2, y_bf16=src2_s)
+            del proj
+            h = h_s = torch._addmm_activation(_b16(b1), src2_s, _b16(w1).t())      # relu(src2 W1^T + b1)
+            ffn = torch.addmm(_b16(b2), h, _b16(w2).t()).view(G, S, D)
         else:
-            qkv, src1_s = lin(src1, in_w, in_b)
-        a = torch.empty((G, S, D), dtype=qkv.dtype, device=dev)
-        lse = torch.empty((G, heads, S), dtype=torch.float32, device=dev)
-        pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
-        proj, a_s = lin(a, out_w, out_b)
-        ssum, src2 = torch.empty_like(x), torch.empty_like(x)
-        st2 = torch.empty((T, 2), dtype=torch.float32, device=dev)
-        pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
-        del proj
-        if bf16:   # h feeds only the next GEMM (and the ReLU mask): bf16 out of the GEMM, bias + ReLU in its epilogue
-            src2_s = _b16(src2.view(T, D))
-            h = h_s = torch._addmm_activation(_b16(b1), src2_s, _b16(w1).t())
-            ffn = _lin(h, w2, b2, True).view(G, S, D)
-        else:
-            h, src2_s = lin(src2, w1, b1)
-            h = torch.relu_(h)
-            ffn, h_s = lin(h, w2, b2)
+            pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
+            qkv = torch.nn.functional.linear(src1, in_w, in_b)
+            a = torch.empty((G, S, D), **f32)
+            pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
+            proj = torch.nn.functional.linear(a, out_w, out_b)
+            pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
+            del proj
+            h = torch.relu_(torch.nn.functional.linear(src2, w1, b1))
+            ffn = torch.nn.functional.linear(h, w2, b2)
+            src1_s, a_s, src2_s, h_s = src1.view(T, D), a.view(T, D), src2.view(T, D), h.view(T, -1)
         if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
-            y = torch.empty((G, D), dtype=torch.float32, device=dev)
+            y = torch.empty((G, D), **f32)
             arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
             pointnet2.add_max_pool(src2, ffn, y, arg, G, S, D)
         else:
@@ -633,44 +638,44 @@ class TransformerBlock(Function):
     def backward(ctx, dy):
         x, st1, src1_s, qkv, lse, a_s, ssum, st2, src2_s, h, h_s, n1w, in_w, out_w, n2w, w1, w2, arg = ctx.saved_tensors
         G, S, D = x.shape
-        T, heads = G * S, ctx.heads
+        T, heads, bf16 = G * S, ctx.heads, ctx.bf16
         hd = D // heads
         dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        b16 = dict(dtype=torch.bfloat16, device=dev)
+        # Each gradient below feeds two GEMMs (an input gradient and a weight gradient).  In dense-bf16 mode `*_g` is
+        # its bf16 copy, written by the kernel that produces the gradient (or the GEMM itself); otherwise the tensor.
         if ctx.pool:   # dy is (G, D): route it to the arg-max tokens (dense (T, D) gradient, written once)
-            dy2 = torch.empty((T, D), dtype=torch.float32, device=dev)
-            pointnet2.max_pool_scatter(dy.contiguous(), arg, dy2, G, S, D)
+            dy2 = torch.empty((T, D), **f32)
+            dy_g = torch.empty((T, D), **b16) if bf16 else dy2
+            pointnet2.max_pool_scatter(dy.contiguous(), arg, dy2, G, S, D, grad_x_bf16=dy_g if bf16 else None)
         else:
             dy2 = dy.contiguous().view(T, D)
-        h2 = h.view(T, -1)
+            dy_g = _b16(dy2) if bf16 else dy2
         # y = src2 + h W2^T + b2
-        bf16 = ctx.bf16
-        op = _b16 if bf16 else (lambda t: t)    # each gradient is cast once for its two GEMMs
-        dy_g = op(dy2)
-        # d_h feeds only GEMMs: in dense-bf16 mode it leaves its GEMM as bf16 (no fp32 round trip, no cast pass)
         d_h = torch.mm(dy_g, _b16(w2)) if bf16 else dy_g.mm(w2)
         gw2, gb2 = _wgrad(h_s, dy_g, w2, True, bf16)
         del dy_g
-        d_h = torch.ops.aten.threshold_backward(d_h, h2, 0)
-        dh_g = d_h
+        d_h = torch.ops.aten.threshold_backward(d_h, h.view(T, -1), 0)
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
-        gw1, gb1 = _wgrad(src2_s, dh_g, w1, True, bf16)
-        d_lin1 = _mm_nn(dh_g, w1, bf16)
-        del d_h, dh_g
+        gw1, gb1 = _wgrad(src2_s, d_h, w1, True, bf16)
+        d_lin1 = torch.mm(d_h, _b16(w1)) if bf16 else d_h.mm(w1)
+        del d_h
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
-        d_s = torch.empty((T, D), dtype=torch.float32, device=dev)
+        d_s = torch.empty((T, D), **f32)
+        ds_g = torch.empty((T, D), **b16) if bf16 else d_s
         gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
-        pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1)
+        pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1, grad_x_bf16=ds_g if bf16 else None)
         del d_lin1
-        ds_g = op(d_s)
-        d_a = (torch.mm(ds_g, _b16(out_w)) if qkv.dtype == torch.bfloat16 else _mm_nn(ds_g, out_w, True)) if bf16 else d_s.mm(out_w)
+        d_a = torch.mm(ds_g, _b16(out_w)) if bf16 else d_s.mm(out_w)
         gwo, gbo = _wgrad(a_s, ds_g, out_w, True, bf16)
         del ds_g
         dqkv = torch.empty_like(qkv)
         pointnet2.group_attention_bwd(qkv, d_a.view(G, S, D), lse, dqkv, G, S, heads, hd)
         del d_a
-        dqkv2 = op(dqkv.view(T, 3 * D))
+        dqkv2 = dqkv.view(T, 3 * D)
         gwi, gbi = _wgrad(src1_s, dqkv2, in_w, True, bf16)
         d_src1 = _mm_nn(dqkv2, in_w, bf16, acc=d_s)     # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv, dqkv2

@@ -106,3 +106,65 @@ def test_transformer_block_with_pool_equals_unfused_max():
     assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
+
+
+@pytest.mark.parametrize("D", [256, 512, 1024])
+@pytest.mark.parametrize("rows", [1, 77, 4099])
+def test_dense_bf16_boundary_variants(D, rows):
+    """pda_layer_norm_{fwd,bwd}_mixed: the same kernels with bf16 tensors on the GEMM side of the boundary.  On inputs
+    that are bf16 values they must reproduce the fp32 entry points bit for bit, and the bf16 copies they emit must be
+    the fp32 results rounded to nearest even (= torch's .bfloat16())."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(D + rows)
+    dev = "cuda"
+    xb = torch.randn(rows, D, device=dev).bfloat16()
+    res = torch.randn(rows, D, device=dev)
+    g, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
+    outs = []
+    for x in (xb.float(), xb):
+        s, y, st = torch.empty(rows, D, device=dev), torch.empty(rows, D, device=dev), torch.empty(rows, 2, device=dev)
+        yb = torch.empty(rows, D, device=dev, dtype=torch.bfloat16) if x.dtype == torch.bfloat16 else None
+        ext.layer_norm_fwd(x, res, g, b, s, y, st, rows, D, 1e-5, y_bf16=yb)
+        outs.append((s, y, st, yb))
+    for u, v in zip(outs[0][:3], outs[1][:3]):
+        assert torch.equal(u, v)
+    assert torch.equal(outs[1][3], outs[0][1].bfloat16())
+    # bf16 copy only (no fp32 y), fp32 x, no residual
+    yb2, st2 = torch.empty(rows, D, device=dev, dtype=torch.bfloat16), torch.empty(rows, 2, device=dev)
+    yref = torch.empty(rows, D, device=dev)
+    ext.layer_norm_fwd(res, None, g, b, None, None, st2, rows, D, 1e-5, y_bf16=yb2)
+    ext.layer_norm_fwd(res, None, g, b, None, yref, st2, rows, D, 1e-5)
+    assert torch.equal(yb2, yref.bfloat16())
+    # backward
+    s, st = outs[0][0], outs[0][2]
+    gy, gy2b = torch.randn(rows, D, device=dev), torch.randn(rows, D, device=dev).bfloat16()
+    scratch = torch.empty(ext.layer_norm_scratch_bytes(D), dtype=torch.uint8, device=dev)
+    res_b = []
+    for g2 in (gy2b.float(), gy2b):
+        gx, gg, gb_ = torch.empty(rows, D, device=dev), torch.empty(D, device=dev), torch.empty(D, device=dev)
+        gxb = torch.empty(rows, D, device=dev, dtype=torch.bfloat16) if g2.dtype == torch.bfloat16 else None
+        ext.layer_norm_bwd(s, gy, g, st, gx, gg, gb_, scratch, rows, D, grad_y2=g2, grad_x_bf16=gxb)
+        res_b.append((gx, gg, gb_, gxb))
+    for u, v in zip(res_b[0][:3], res_b[1][:3]):
+        assert torch.equal(u, v)
+    assert torch.equal(res_b[1][3], res_b[0][0].bfloat16())
+
+
+@pytest.mark.parametrize("G,S,D", [(5, 16, 256), (301, 32, 512), (1, 8, 4)])
+def test_add_max_pool_dense_bf16_variants(G, S, D):
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(G + S)
+    a = torch.randn(G, S, D, device="cuda")
+    bb = torch.randn(G, S, D, device="cuda").bfloat16()
+    outs = []
+    for b in (bb.float(), bb):
+        y, arg = torch.empty(G, D, device="cuda"), torch.empty(G, D, device="cuda", dtype=torch.uint8)
+        ext.add_max_pool(a, b, y, arg, G, S, D)
+        outs.append((y, arg))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    go = torch.randn(G, D, device="cuda")
+    gx, gx2 = torch.empty(G, S, D, device="cuda"), torch.empty(G, S, D, device="cuda")
+    gxb = torch.empty(G, S, D, device="cuda", dtype=torch.bfloat16)
+    ext.max_pool_scatter(go, outs[0][1], gx, G, S, D)
+    ext.max_pool_scatter(go, outs[0][1], gx2, G, S, D, grad_x_bf16=gxb)
+    assert torch.equal(gx, gx2) and torch.equal(gxb, gx.bfloat16())
