@@ -16,8 +16,10 @@ Workloads (--workload):
   backbone           full backbone forward+backward (default; BASELINE's metric).
   backbone_infer     backbone forward, eval BN, fused SA kernel (BASELINE configs[1]).
   train_step         backbone forward+backward + grad clip + adam_onecycle step (csrc/optim.hip).
-  backbone_bf16      backbone forward+backward in dense-bf16 mode (bf16 GEMM operands, fp32 accumulate/outputs on
-                     the large projections; activations, statistics and all operators fp32).
+  backbone_bf16      backbone forward+backward in dense-bf16 mode (DESIGN.md "Dense-bf16 mode": bf16 GEMMs with fp32
+                     accumulation, GEMM-adjacent tensors stored as bf16; residual stream, statistics and the
+                     kernels' arithmetic fp32).
+  backbone_infer_bf16   backbone_infer in dense-bf16 mode.
   kitti_train_bf16   train_step on the KITTI yaml in dense-bf16 mode (use --batch 4).
   detector_train     backbone + IA-SSD head (target assignment, all losses) + grad clip + adam_onecycle:
                      the reference's whole training iteration on synthetic scenes and boxes.

@@ -51,7 +51,7 @@ class BackboneWorkload:
         self.amp = False            # `amp` selects the dense-bf16 mode, not torch.autocast (see pointnet2_utils.DENSE_BF16)
         from . import pointnet2_utils as _pu
         _pu.DENSE_BF16 = bool(amp)
-        self.dtype = "bf16 GEMM operands, f32 accumulate / activations / ops" if amp else "f32"
+        self.dtype = "bf16 GEMMs (f32 accumulate) and GEMM-adjacent tensors; residual stream, statistics and kernel arithmetic f32" if amp else "f32"
         self.tuned = enable_tuned_gemms() if os.environ.get("PDA_NO_TUNED_GEMMS") != "1" else False
         torch.manual_seed(1234)  # same initial weights on every rank
         model, self.cfg = build_backbone(cfg)

@@ -654,7 +654,10 @@ class TransformerBlock(Function):
             dy_g = _b16(dy2) if bf16 else dy2
         # y = src2 + h W2^T + b2
         d_h = torch.mm(dy_g, _b16(w2)) if bf16 else dy_g.mm(w2)
-        gw2, gb2 = _wgrad(h_s, dy_g, w2, True, bf16)
+        if bf16 and ctx.pool:   # the scattered gradient's column sums are those of the (G, D) tensor it was scattered from
+            gw2, gb2 = _wgrad(h_s, dy_g, w2, False, True)[0], dy.sum(0)
+        else:
+            gw2, gb2 = _wgrad(h_s, dy_g, w2, True, bf16)
         del dy_g
         d_h = torch.ops.aten.threshold_backward(d_h, h.view(T, -1), 0)
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward

@@ -123,8 +123,8 @@ def test_fused_and_unfused_training_steps_agree():
 
 
 def test_dense_bf16_mode_tracks_fp32():
-    """pointnet2_utils.DENSE_BF16: bf16 GEMM operands (fp32 accumulate / outputs) in the 1x1 convolutions and
-    projections, everything else fp32.  Layers 0-1 of the backbone against the fp32 run: bf16-level agreement."""
+    """pointnet2_utils.DENSE_BF16 (DESIGN.md "Dense-bf16 mode"): bf16 GEMMs with fp32 accumulation, GEMM-adjacent tensors
+    stored as bf16, everything else fp32.  Layers 0-1 of the backbone against the fp32 run: bf16-level agreement."""
     from pdanet_amd import synth, pointnet2_utils as pu
     from pdanet_amd.backbone import build_backbone
     B, N = 2, 4096
