@@ -40,7 +40,7 @@ class BackboneWorkload:
     With world > 1 the model is wrapped in DDP (RCCL gradient all-reduce over xGMI).
     """
 
-    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml"):
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml"):
         from . import synth
         from .backbone import build_backbone
         self.B, self.N = batch, n_points
@@ -48,10 +48,9 @@ class BackboneWorkload:
             "once%d_b%d_backbone_fwd_bwd" % (n_points, batch)
         self.device = device
         self.cfg_name = cfg
-        self.amp = False            # `amp` selects the dense-bf16 mode, not torch.autocast (see pointnet2_utils.DENSE_BF16)
         from . import pointnet2_utils as _pu
-        _pu.DENSE_BF16 = bool(amp)
-        self.dtype = "bf16 GEMMs (f32 accumulate) and GEMM-adjacent tensors; residual stream, statistics and kernel arithmetic f32" if amp else "f32"
+        _pu.DENSE_BF16 = bool(dense_bf16)       # DESIGN.md "Dense-bf16 mode" (not torch.autocast)
+        self.dtype = "bf16 GEMMs (f32 accumulate) and GEMM-adjacent tensors; residual stream, statistics and kernel arithmetic f32" if dense_bf16 else "f32"
         self.tuned = enable_tuned_gemms() if os.environ.get("PDA_NO_TUNED_GEMMS") != "1" else False
         torch.manual_seed(1234)  # same initial weights on every rank
         model, self.cfg = build_backbone(cfg)
@@ -144,8 +143,7 @@ class BackboneWorkload:
         model = self.ddp if self.ddp is not None else self.model
         for p in self.model.parameters():
             p.grad = None
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
+        bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         loss = self.loss_of(bd)
         loss.backward()
         return loss
@@ -204,7 +202,7 @@ class BackboneInferWorkload(BackboneWorkload):
     the fused SA-scale kernel on layers 0 and 5."""
 
     def __init__(self, batch, n_points, device, rank, world, dense_bf16=False):
-        super().__init__(batch, n_points, device, rank, world, amp=dense_bf16)
+        super().__init__(batch, n_points, device, rank, world, dense_bf16=dense_bf16)
         from . import fused_ops
         self.fused_ops = fused_ops
         self.name = self.name.replace("fwd_bwd", "fwd_eval_fused")
@@ -254,13 +252,13 @@ class TrainStepWorkload(BackboneWorkload):
     OPTIM = dict(OPTIMIZER="adam_onecycle", LR=0.01, WEIGHT_DECAY=0.01, MOMS=[0.95, 0.85], PCT_START=0.4,
                  DIV_FACTOR=10, GRAD_NORM_CLIP=10)   # once/kitti PDA-SSD.yaml OPTIMIZATION
 
-    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml", dataset="once"):
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml", dataset="once"):
         from . import optimization, parallel, synth
-        super().__init__(batch, n_points, device, rank, 1, amp=amp, cfg=cfg)
+        super().__init__(batch, n_points, device, rank, 1, dense_bf16=dense_bf16, cfg=cfg)
         if dataset != "once":
             self.points_np = synth.batch_points(batch, n_points, config_id=3 + 10 * rank, dist="L", dataset=dataset)
             self.points = torch.from_numpy(self.points_np).to(device)
-        self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if amp else "")
+        self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
         self.opt = optimization.build_optimizer(self.model, self.OPTIM)     # flat buffers BEFORE DDP
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.OPTIM)
         self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
@@ -270,8 +268,7 @@ class TrainStepWorkload(BackboneWorkload):
         model = self.ddp if self.ddp is not None else self.model
         self.sched.step(self.it)
         self.opt.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
+        bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         loss = self.loss_of(bd)
         loss.backward()
         self.opt.step()
@@ -285,9 +282,9 @@ class DetectorTrainWorkload(TrainStepWorkload):
     clipping and the adam_onecycle step -- tools/train_utils/train_utils.py:34-60 with model_func =
     model_fn_decorator (pcdet/models/__init__.py).  No host synchronisation inside the step."""
 
-    def __init__(self, batch, n_points, device, rank, world, amp=False, cfg="once_pda_ssd.yaml", dataset="once"):
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml", dataset="once"):
         from . import detector, optimization, parallel, synth
-        BackboneWorkload.__init__(self, batch, n_points, device, rank, 1, amp=amp, cfg=cfg)
+        BackboneWorkload.__init__(self, batch, n_points, device, rank, 1, dense_bf16=dense_bf16, cfg=cfg)
         self.points_np = synth.batch_points(batch, n_points, config_id=(2 if dataset == "once" else 3) + 10 * rank,
                                             dist="L", dataset=dataset)
         self.points = torch.from_numpy(self.points_np).to(device)
@@ -295,7 +292,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         torch.manual_seed(1234)
         model, self.cfg = detector.build_detector(cfg)
         self.model = model.to(device).train()
-        self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if amp else "")
+        self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
         self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
         self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
@@ -305,8 +302,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         model = self.ddp if self.ddp is not None else self.model
         self.sched.step(self.it)
         self.opt.zero_grad()
-        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.amp):
-            ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt, 'inputs_resident': True})
+        ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt, 'inputs_resident': True})
         ret['loss'].backward()
         self.opt.step()
         self.it += 1
@@ -318,19 +314,19 @@ def create(name, batch, n_points, device, rank, world):
     if name == "detector_train":
         return DetectorTrainWorkload(batch, n_points, device, rank, world)
     if name == "kitti_detector_train_bf16":
-        return DetectorTrainWorkload(batch, n_points, device, rank, world, amp=True, cfg="kitti_pda_ssd.yaml",
+        return DetectorTrainWorkload(batch, n_points, device, rank, world, dense_bf16=True, cfg="kitti_pda_ssd.yaml",
                                      dataset="kitti")
     if name == "train_step":
         return TrainStepWorkload(batch, n_points, device, rank, world)
     if name == "kitti_train_bf16":
-        return TrainStepWorkload(batch, n_points, device, rank, world, amp=True, cfg="kitti_pda_ssd.yaml",
+        return TrainStepWorkload(batch, n_points, device, rank, world, dense_bf16=True, cfg="kitti_pda_ssd.yaml",
                                  dataset="kitti")
     if name == "backbone_infer":
         return BackboneInferWorkload(batch, n_points, device, rank, world)
     if name == "backbone_infer_bf16":
         return BackboneInferWorkload(batch, n_points, device, rank, world, dense_bf16=True)
     if name == "backbone":
-        return BackboneWorkload(batch, n_points, device, rank, world, amp=False)
+        return BackboneWorkload(batch, n_points, device, rank, world, dense_bf16=False)
     if name == "backbone_bf16":
-        return BackboneWorkload(batch, n_points, device, rank, world, amp=True)
+        return BackboneWorkload(batch, n_points, device, rank, world, dense_bf16=True)
     raise ValueError("unknown workload %r" % name)
