@@ -93,20 +93,65 @@ def _bn_relu_lastdim(bn, x):
     return F.relu(_bn_lastdim(bn, x))
 
 
+FOLD_EVAL_BN = True   # inference: BatchNorm (running statistics) folded into the preceding 1x1 convolution
+
+
+def _folded_conv_bn(conv, bn):
+    """(W', b') with W' x + b' == BN_eval(conv(x)): W' = W * s, b' = (conv.bias - running_mean) * s + beta,
+    s = gamma / sqrt(running_var + eps).  Cached on the BN module, keyed on the version counters of every tensor
+    involved (an optimizer step, a load_state_dict or a training-mode forward invalidates it)."""
+    tensors = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+    cache = bn.__dict__.get("_pda_folded")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+            w = (conv.weight.flatten(1) * s[:, None]).contiguous()
+            b = bn.bias - bn.running_mean * s
+            if conv.bias is not None:
+                b = b + conv.bias * s
+        cache = (key, w, b.contiguous())
+        bn.__dict__["_pda_folded"] = cache
+    return cache[1], cache[2]
+
+
+def _can_fold(conv, bn):
+    return (FOLD_EVAL_BN and not bn.training and not torch.is_grad_enabled() and bn.affine and bn.running_mean is not None
+            and conv.weight.is_cuda)
+
+
+def _linear_relu(x, w, b):
+    """relu(x W^T + b) over the last dim; fp32 outside the dense-bf16 sizes: bias and ReLU in the GEMM epilogue."""
+    if b is not None and x.dtype == torch.float32 and not pointnet2_utils._dense_bf16(x, w) and not torch.is_autocast_enabled():
+        y = torch._addmm_activation(b, x.reshape(-1, x.shape[-1]), w.t())
+        return y.view(*x.shape[:-1], w.shape[0])
+    return torch.relu_(pointnet2_utils.linear(x, w, b))
+
+
 def _mlp_lastdim(layers, x):
     """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x."""
     layers = list(layers)
-    skip = False
+    skip = 0
     for k, m in enumerate(layers):
         if skip:
-            skip = False
+            skip -= 1
             continue
         if isinstance(m, (nn.Conv2d, nn.Conv1d)):
+            nxt = layers[k + 1] if k + 1 < len(layers) else None
+            if isinstance(nxt, (nn.BatchNorm1d, nn.BatchNorm2d)) and _can_fold(m, nxt):
+                w, b = _folded_conv_bn(m, nxt)
+                if k + 2 < len(layers) and isinstance(layers[k + 2], nn.ReLU):
+                    x = _linear_relu(x, w, b)
+                    skip = 2
+                else:
+                    x = pointnet2_utils.linear(x, w, b)
+                    skip = 1
+                continue
             x = pointnet2_utils.linear(x, m.weight.flatten(1), m.bias)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             if k + 1 < len(layers) and isinstance(layers[k + 1], nn.ReLU):
                 x = _bn_relu_lastdim(m, x)
-                skip = True
+                skip = 1
             else:
                 x = _bn_lastdim(m, x)
         elif isinstance(m, nn.ReLU):
@@ -123,7 +168,7 @@ def _transformer_batch_first(tr, x, pool=False):
     attn = tr.self_attn
     assert attn.dropout == 0.0 or not tr.training
     D, H = attn.embed_dim, attn.num_heads
-    if (FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL and torch.is_grad_enabled()
+    if (FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL
             and pointnet2_utils.TransformerBlock.supported(x, H)):
         return pointnet2_utils.transformer_block(tr, x, pool)
     fused_ln = FUSED_LAYER_NORM and pointnet2_utils.LayerNormResidual.supported(x, D) and not torch.is_autocast_enabled()
@@ -563,7 +608,10 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 dscale = pointnet2_utils.densitynet(dn, dscale)            # 4 + 5 launches instead of ~45
             else:
                 for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
-                    dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
+                    if _can_fold(conv, bn):
+                        dscale = _linear_relu(dscale, *_folded_conv_bn(conv, bn))
+                    else:
+                        dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
             if pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
