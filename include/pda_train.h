@@ -44,6 +44,14 @@ int pda_bn_relu_fwd(const float *x, const float *gamma, const float *beta, float
 int pda_bn_relu_bwd(const float *x, const float *grad_y, const float *gamma, const float *beta,
                     const float *mean_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
                     void *scratch, int64_t rows, int c, pda_stream_t stream);
+/* Dense-bf16 mode variants (same kernels and fp32 / double arithmetic): x may be the bf16 output of a GEMM, y may be
+ * written as bf16 (when it only feeds the next GEMM), grad_y may be bf16; grad_x has the element type of x. */
+int pda_bn_relu_fwd_mixed(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *running_mean,
+                          float *running_var, void *y, int y_is_bf16, float *mean_invstd, void *scratch,
+                          int64_t rows, int c, float eps, float momentum, pda_stream_t stream);
+int pda_bn_relu_bwd_mixed(const void *x, int x_is_bf16, const void *grad_y, int grad_y_is_bf16, const float *gamma,
+                          const float *beta, const float *mean_invstd, void *grad_x, float *grad_gamma,
+                          float *grad_beta, void *scratch, int64_t rows, int c, pda_stream_t stream);
 
 /* ---- LayerNorm over the last dimension with optional fused residual add (MI355X extension) ----------
  * nn.LayerNorm(D) of TransformerEncoderLayerPreNorm (PointFormer.py:17-18,29,33): x (rows, D) [+ residual

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -46,7 +46,9 @@ SIGNATURES = {
     "pda_grad_norm": [_vp, ctypes.c_int64, _vp, _vp, _vp],
     "pda_bn_relu_scratch_bytes": [_i],
     "pda_bn_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
-    "pda_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
+    "pda_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],    "pda_bn_relu_fwd_mixed": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
+    "pda_bn_relu_bwd_mixed": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
+
     "pda_layer_norm_scratch_bytes": [_i],
     "pda_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],
     "pda_layer_norm_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],

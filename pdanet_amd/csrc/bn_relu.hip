@@ -41,8 +41,9 @@ __device__ __forceinline__ void block_reduce_cols(double (&a)[4], double (&b)[4]
 
 // BWD == false: partial[blk][0][c] = sum x, [1][c] = sum x^2
 // BWD == true : with dyh = dy * [(x - mean) * invstd * gamma + beta > 0]: [0][c] = sum dyh, [1][c] = sum dyh * xhat
-template <bool BWD>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+// TX / TD: element types of x and dy -- float, or bf16 where the tensor is the output of a bf16 GEMM (dense-bf16 mode)
+template <bool BWD, typename TX, typename TD>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const TX* __restrict__ x, const TD* __restrict__ dy,
                                                         const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, double* __restrict__ partial, BnShape s) {
     __shared__ double lds[2 * 256 * 4];
@@ -58,12 +59,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
             be = reinterpret_cast<const float4*>(beta)[col];
         }
         for (int64_t r = (int64_t)blockIdx.x * s.rpb + r0; r < s.rows; r += (int64_t)gridDim.x * s.rpb) {
-            const float4 v = reinterpret_cast<const float4*>(x + r * s.c)[col];
+            const float4 v = load4(x + r * s.c + 4 * col);
             if (!BWD) {
                 a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
                 b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
             } else {
-                const float4 d = reinterpret_cast<const float4*>(dy + r * s.c)[col];
+                const float4 d = load4(dy + r * s.c + 4 * col);
                 const float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
                 const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {be.x, be.y, be.z, be.w}, dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -143,11 +144,11 @@ __global__ __launch_bounds__(512) void bn_finalize_bwd_kernel(const double* __re
 
 // BWD == false: y = relu((x - mean) * invstd * gamma + beta)
 // BWD == true : dx = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat))
-template <bool BWD>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+template <bool BWD, typename TX, typename TD, typename TO>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, const TD* __restrict__ dy,
                                                        const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ sums,
-                                                       float* __restrict__ out, BnShape s) {
+                                                       TO* __restrict__ out, BnShape s) {
     const int tid = threadIdx.x;
     const int col = tid % s.cg, r0 = tid / s.cg;
     const float4 mu = reinterpret_cast<const float4*>(mean_invstd)[col], is = reinterpret_cast<const float4*>(mean_invstd + s.c)[col];
@@ -157,14 +158,14 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
     const float muv[4] = {mu.x, mu.y, mu.z, mu.w}, isv[4] = {is.x, is.y, is.z, is.w}, gv[4] = {g.x, g.y, g.z, g.w},
                 bv[4] = {be.x, be.y, be.z, be.w}, m1v[4] = {m1.x, m1.y, m1.z, m1.w}, m2v[4] = {m2.x, m2.y, m2.z, m2.w};
     for (int64_t r = (int64_t)blockIdx.x * s.rpb + r0; r < s.rows; r += (int64_t)gridDim.x * s.rpb) {
-        const float4 v = reinterpret_cast<const float4*>(x + r * s.c)[col];
+        const float4 v = load4(x + r * s.c + 4 * col);
         const float xv[4] = {v.x, v.y, v.z, v.w};
         float o[4];
         if (!BWD) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaxf((xv[k] - muv[k]) * isv[k] * gv[k] + bv[k], 0.f);
         } else {
-            const float4 d = reinterpret_cast<const float4*>(dy + r * s.c)[col];
+            const float4 d = load4(dy + r * s.c + 4 * col);
             const float dv[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
                 o[k] = gv[k] * isv[k] * (dyh - m1v[k] - xh * m2v[k]);
             }
         }
-        reinterpret_cast<float4*>(out + r * s.c)[col] = make_float4(o[0], o[1], o[2], o[3]);
+        store4(out + r * s.c + 4 * col, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -196,42 +197,84 @@ PDA_API int64_t pda_bn_relu_scratch_bytes(int c) {
     return (int64_t)pda::BN_BLOCKS * 2 * cc * (int64_t)sizeof(double) + 2 * cc * (int64_t)sizeof(float);
 }
 
+namespace pda {
+
+template <typename T> static bool bn_aligned(const T* p) { return ((uintptr_t)p & (4 * sizeof(T) - 1)) == 0; }
+
+template <typename TX, typename TY>
+static int launch_bn_relu_fwd(const TX* x, const float* gamma, const float* beta, float* running_mean, float* running_var, TY* y,
+                              float* mean_invstd, void* scratch, int64_t rows, int c, float eps, float momentum, hipStream_t st,
+                              const char* what) {
+    BnShape s;
+    if (int rc = bn_shape(rows, c, s, what)) return rc;
+    PDA_REQUIRE(x && gamma && beta && y && mean_invstd && scratch, "%s: null pointer", what);
+    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running_mean/var must come together", what);
+    PDA_REQUIRE(bn_aligned(x) && bn_aligned(y) && (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
+                "%s: pointers must be 16-byte aligned (8 for bf16 tensors)", what);
+    const int grid = bn_grid(s);
+    hipLaunchKernelGGL((bn_reduce_kernel<false, TX, float>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
+                       mean_invstd, running_mean, running_var);
+    hipLaunchKernelGGL((bn_apply_kernel<false, TX, float, TY>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, mean_invstd, gamma, beta,
+                       (const float*)nullptr, y, s);
+    return check_launch(what);
+}
+
+template <typename TX, typename TD>
+static int launch_bn_relu_bwd(const TX* x, const TD* grad_y, const float* gamma, const float* beta, const float* mean_invstd, TX* grad_x,
+                              float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c, hipStream_t st, const char* what) {
+    BnShape s;
+    if (int rc = bn_shape(rows, c, s, what)) return rc;
+    PDA_REQUIRE(x && grad_y && gamma && beta && mean_invstd && grad_x && grad_gamma && grad_beta && scratch, "%s: null pointer", what);
+    PDA_REQUIRE(bn_aligned(x) && bn_aligned(grad_y) && bn_aligned(grad_x) && (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
+                "%s: pointers must be 16-byte aligned (8 for bf16 tensors)", what);
+    const int grid = bn_grid(s);
+    // the per-channel means of the second pass live behind the partials in the scratch buffer
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)BN_BLOCKS * 2 * c);
+    hipLaunchKernelGGL((bn_reduce_kernel<true, TX, TD>), dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, (double*)scratch, s);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, grad_gamma, grad_beta,
+                       sums);
+    hipLaunchKernelGGL((bn_apply_kernel<true, TX, TD, TX>), dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, sums, grad_x, s);
+    return check_launch(what);
+}
+
+}  // namespace pda
+
 PDA_API int pda_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
                             float* y, float* mean_invstd, void* scratch, int64_t rows, int c, float eps, float momentum,
                             pda_stream_t stream) {
-    pda::BnShape s;
-    if (int st = pda::bn_shape(rows, c, s, "pda_bn_relu_fwd")) return st;
-    PDA_REQUIRE(x && gamma && beta && y && mean_invstd && scratch, "pda_bn_relu_fwd: null pointer");
-    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "pda_bn_relu_fwd: running_mean/var must come together");
-    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
-                "pda_bn_relu_fwd: pointers must be 16-byte aligned");
-    const int grid = pda::bn_grid(s);
-    hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(pda::bn_reduce_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
-    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
-                       mean_invstd, running_mean, running_var);
-    hipLaunchKernelGGL(pda::bn_apply_kernel<false>, dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, mean_invstd, gamma, beta,
-                       (const float*)nullptr, y, s);
-    return pda::check_launch("pda_bn_relu_fwd");
+    return pda::launch_bn_relu_fwd<float, float>(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum,
+                                                 (hipStream_t)stream, "pda_bn_relu_fwd");
 }
 
 PDA_API int pda_bn_relu_bwd(const float* x, const float* grad_y, const float* gamma, const float* beta, const float* mean_invstd,
                             float* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c,
                             pda_stream_t stream) {
-    pda::BnShape s;
-    if (int st = pda::bn_shape(rows, c, s, "pda_bn_relu_bwd")) return st;
-    PDA_REQUIRE(x && grad_y && gamma && beta && mean_invstd && grad_x && grad_gamma && grad_beta && scratch,
-                "pda_bn_relu_bwd: null pointer");
-    PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
-                "pda_bn_relu_bwd: pointers must be 16-byte aligned");
-    const int grid = pda::bn_grid(s);
+    return pda::launch_bn_relu_bwd<float, float>(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c,
+                                                 (hipStream_t)stream, "pda_bn_relu_bwd");
+}
+
+PDA_API int pda_bn_relu_fwd_mixed(const void* x, int x_is_bf16, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, void* y, int y_is_bf16, float* mean_invstd, void* scratch, int64_t rows, int c,
+                                  float eps, float momentum, pda_stream_t stream) {
+    using pda::bf16_t;
     hipStream_t st = (hipStream_t)stream;
-    // the per-channel means of the second pass live behind the partials in the scratch buffer
-    float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)pda::BN_BLOCKS * 2 * c);
-    hipLaunchKernelGGL(pda::bn_reduce_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, (double*)scratch, s);
-    hipLaunchKernelGGL(pda::bn_finalize_bwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, grad_gamma,
-                       grad_beta, sums);
-    hipLaunchKernelGGL(pda::bn_apply_kernel<true>, dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, sums, grad_x, s);
-    return pda::check_launch("pda_bn_relu_bwd");
+    const char* what = "pda_bn_relu_fwd_mixed";
+#define PDA_BN_FWD(TX, TY) pda::launch_bn_relu_fwd<TX, TY>((const TX*)x, gamma, beta, running_mean, running_var, (TY*)y, mean_invstd, scratch, rows, c, eps, momentum, st, what)
+    if (x_is_bf16) return y_is_bf16 ? PDA_BN_FWD(bf16_t, bf16_t) : PDA_BN_FWD(bf16_t, float);
+    return y_is_bf16 ? PDA_BN_FWD(float, bf16_t) : PDA_BN_FWD(float, float);
+#undef PDA_BN_FWD
+}
+
+PDA_API int pda_bn_relu_bwd_mixed(const void* x, int x_is_bf16, const void* grad_y, int grad_y_is_bf16, const float* gamma,
+                                  const float* beta, const float* mean_invstd, void* grad_x, float* grad_gamma, float* grad_beta,
+                                  void* scratch, int64_t rows, int c, pda_stream_t stream) {
+    using pda::bf16_t;
+    hipStream_t st = (hipStream_t)stream;
+    const char* what = "pda_bn_relu_bwd_mixed";
+#define PDA_BN_BWD(TX, TD) pda::launch_bn_relu_bwd<TX, TD>((const TX*)x, (const TD*)grad_y, gamma, beta, mean_invstd, (TX*)grad_x, grad_gamma, grad_beta, scratch, rows, c, st, what)
+    if (x_is_bf16) return grad_y_is_bf16 ? PDA_BN_BWD(bf16_t, bf16_t) : PDA_BN_BWD(bf16_t, float);
+    return grad_y_is_bf16 ? PDA_BN_BWD(float, bf16_t) : PDA_BN_BWD(float, float);
+#undef PDA_BN_BWD
 }

@@ -214,22 +214,42 @@ def bn_relu_scratch_bytes(c):
     return int(_lib.load().pda_bn_relu_scratch_bytes(int(c)))
 
 
+def _io(t, name):
+    """pointer + is-bf16 flag of a tensor that may be fp32 or bf16 (dense-bf16 mode boundary tensors)."""
+    if t.dtype == torch.bfloat16:
+        return _chk(t, name, torch.bfloat16), 1
+    return _chk(t, name, F32), 0
+
+
 def bn_relu_fwd(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum):
-    """MI355X extension: training-mode BatchNorm + ReLU over the last dim (csrc/bn_relu.hip)."""
+    """MI355X extension: training-mode BatchNorm + ReLU over the last dim (csrc/bn_relu.hip).  x / y fp32, or bf16 where
+    they sit next to a bf16 GEMM (dense-bf16 mode)."""
     _numel_ok(x, rows * c, "x"); _numel_ok(y, rows * c, "y"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
     rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
     rv = None if running_var is None else _chk(running_var, "running_var", F32)
-    _call("pda_bn_relu_fwd", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv,
-          _chk(y, "y", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c,
-          float(eps), float(momentum))
+    if x.dtype == F32 and y.dtype == F32:
+        _call("pda_bn_relu_fwd", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv,
+              _chk(y, "y", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c,
+              float(eps), float(momentum))
+        return 1
+    (xp, xb), (yp, yb) = _io(x, "x"), _io(y, "y")
+    _call("pda_bn_relu_fwd_mixed", x, xp, xb, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv, yp, yb,
+          _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c, float(eps), float(momentum))
     return 1
 
 
 def bn_relu_bwd(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c):
+    """grad_x has the dtype of x; grad_y may be fp32 or bf16."""
     _numel_ok(x, rows * c, "x"); _numel_ok(grad_y, rows * c, "grad_y"); _numel_ok(grad_x, rows * c, "grad_x")
-    _call("pda_bn_relu_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32),
-          _chk(beta, "beta", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", F32),
-          _chk(grad_gamma, "grad_gamma", F32), _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c)
+    if x.dtype == F32 and grad_y.dtype == F32:
+        _call("pda_bn_relu_bwd", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32),
+              _chk(beta, "beta", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", F32),
+              _chk(grad_gamma, "grad_gamma", F32), _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c)
+        return 1
+    (xp, xb), (gp, gb) = _io(x, "x"), _io(grad_y, "grad_y")
+    _call("pda_bn_relu_bwd_mixed", x, xp, xb, gp, gb, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32),
+          _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", x.dtype), _chk(grad_gamma, "grad_gamma", F32),
+          _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c)
     return 1
 
 

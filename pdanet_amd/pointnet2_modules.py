@@ -86,11 +86,18 @@ FUSED_GEOMETRY = True   # one kernel for the PDA grouper's density / direction /
 FUSED_LAYER_NORM = True   # csrc/layer_norm.hip (with the residual add fused in) instead of F.layer_norm
 
 
-def _bn_relu_lastdim(bn, x):
+def _bn_relu_lastdim(bn, x, out_bf16=False):
     """relu(bn(x)) over the last dim: one fused kernel pair in training mode, else torch."""
     if FUSED_BN_RELU and pointnet2_utils.BatchNormReLU.supported(x, bn):
-        return pointnet2_utils.batch_norm_relu(bn, x)
+        return pointnet2_utils.batch_norm_relu(bn, x, out_bf16)
     return F.relu(_bn_lastdim(bn, x))
+
+
+def _bf16_boundary(x, conv, bn):
+    """Dense-bf16 training: may the output of `conv` over x stay bf16 on its way into the fused BN+ReLU kernel?"""
+    w = conv.weight.flatten(1)
+    return (pointnet2_utils.DENSE_BF16 and FUSED_BN_RELU and torch.is_grad_enabled() and pointnet2_utils._dense_bf16(x, w)
+            and pointnet2_utils.BatchNormReLU.supported_module(bn, w.shape[0]))
 
 
 FOLD_EVAL_BN = True   # inference: BatchNorm (running statistics) folded into the preceding 1x1 convolution
@@ -147,10 +154,16 @@ def _mlp_lastdim(layers, x):
                     x = pointnet2_utils.linear(x, w, b)
                     skip = 1
                 continue
-            x = pointnet2_utils.linear(x, m.weight.flatten(1), m.bias)
+            relu_next = k + 2 < len(layers) and isinstance(layers[k + 2], nn.ReLU)
+            boundary = isinstance(nxt, (nn.BatchNorm1d, nn.BatchNorm2d)) and relu_next and _bf16_boundary(x, m, nxt)
+            x = pointnet2_utils.linear(x, m.weight.flatten(1), m.bias, out_bf16=boundary)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             if k + 1 < len(layers) and isinstance(layers[k + 1], nn.ReLU):
-                x = _bn_relu_lastdim(m, x)
+                # dense-bf16 mode: y goes out as bf16 when its only consumer is the next bf16 GEMM of the chain
+                after = layers[k + 2] if k + 2 < len(layers) else None
+                out_b = (x.dtype == torch.bfloat16 and isinstance(after, (nn.Conv2d, nn.Conv1d))
+                         and pointnet2_utils._dense_bf16(x, after.weight.flatten(1)))
+                x = _bn_relu_lastdim(m, x, out_b)
                 skip = 1
             else:
                 x = _bn_lastdim(m, x)

@@ -253,17 +253,21 @@ class BatchNormReLU(Function):
     of the channel-major tensor; running statistics updated in place)."""
 
     @staticmethod
-    def supported(x, bn):
-        c = x.shape[-1]
-        return (x.is_cuda and x.dtype == torch.float32 and bn.training and bn.affine and bn.momentum is not None
-                and 4 <= c <= 1024 and (c & (c - 1)) == 0 and x.numel() > 0)
+    def supported_module(bn, c):
+        return bn.training and bn.affine and bn.momentum is not None and 4 <= c <= 1024 and (c & (c - 1)) == 0
 
     @staticmethod
-    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+    def supported(x, bn):
+        # x: fp32, or bf16 where it is the output of a dense-bf16 GEMM (`linear(..., out_bf16=True)`)
+        return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.numel() > 0
+                and BatchNormReLU.supported_module(bn, x.shape[-1]))
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, out_bf16=False):
         x = x.contiguous()
         c = x.shape[-1]
         rows = x.numel() // c
-        y = torch.empty_like(x)
+        y = torch.empty(x.shape, dtype=torch.bfloat16 if out_bf16 else torch.float32, device=x.device)
         stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
         scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
         pointnet2.bn_relu_fwd(x, weight, bias, running_mean, running_var, y, stats, scratch, rows, c, eps, momentum)
@@ -279,7 +283,7 @@ class BatchNormReLU(Function):
         gw, gb = torch.empty_like(weight), torch.empty_like(bias)
         scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
         pointnet2.bn_relu_bwd(x, grad_y.contiguous(), weight, bias, stats, grad_x, gw, gb, scratch, rows, c)
-        return grad_x, gw, gb, None, None, None, None
+        return grad_x, gw, gb, None, None, None, None, None
 
 
 # num_batches_tracked bookkeeping: 51 one-element `add_` launches per step when every layer bumps its own
@@ -295,11 +299,12 @@ def bump_bn_counter(bn):
             bn.num_batches_tracked.add_(1)
 
 
-def batch_norm_relu(bn, x):
-    """relu(bn(x)) for an nn.BatchNorm{1,2}d module over the LAST dim of x (training mode, fp32)."""
+def batch_norm_relu(bn, x, out_bf16=False):
+    """relu(bn(x)) for an nn.BatchNorm{1,2}d module over the LAST dim of x (training mode; fp32 arithmetic).
+    out_bf16: write the result as bf16 (dense-bf16 mode, when it only feeds the next bf16 GEMM)."""
     bump_bn_counter(bn)
     rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
-    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
+    return BatchNormReLU.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, out_bf16)
 
 
 class AssembleTokens(Function):
@@ -458,7 +463,7 @@ BF16_MIN_FEATURES = 128
 
 
 def _dense_bf16(x, weight=None):
-    if not (DENSE_BF16 and x.is_cuda and x.dtype == torch.float32 and not torch.is_autocast_enabled()):
+    if not (DENSE_BF16 and x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and not torch.is_autocast_enabled()):
         return False
     if x.numel() // max(1, x.shape[-1]) < BF16_MIN_TOKENS:
         return False
@@ -503,15 +508,24 @@ def _lin(x, w, b, bf16, keep=False):
 
 
 class LinearBF16(Function):
-    """y = x W^T + b with bf16 GEMM operands (fp32 accumulate / output) in the forward, the input gradient and the
-    weight gradient (`_wgrad_bf16`); keeps only the bf16 copy of x for backward."""
+    """y = x W^T + b with bf16 GEMM operands (fp32 accumulation) in the forward, the input gradient and the weight
+    gradient (`_wgrad_bf16`); keeps only the bf16 copy of x for backward.  x may already be bf16 (the output of a kernel
+    that emits the operand copy); out_bf16: y leaves the GEMM as bf16 (its consumer reads bf16, e.g. `batch_norm_relu`).
+    The input gradient has the dtype of x."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        y, xb = _lin(x, weight, bias, True, keep=True)
+    def forward(ctx, x, weight, bias, out_bf16=False):
+        xb = _b16(x.reshape(-1, x.shape[-1]))
+        if out_bf16:
+            wb = _b16(weight)
+            y = torch.mm(xb, wb.t()) if bias is None else torch.addmm(_b16(bias), xb, wb.t())
+        else:
+            y = _mm_nt(xb, weight, True)
+            if bias is not None:
+                y.add_(bias)
         ctx.save_for_backward(xb, weight)
-        ctx.has_bias, ctx.x_shape = bias is not None, x.shape
-        return y
+        ctx.has_bias, ctx.x_shape, ctx.x_bf16 = bias is not None, x.shape, x.dtype == torch.bfloat16
+        return y.view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -520,16 +534,20 @@ class LinearBF16(Function):
         g2 = _b16(grad_out.reshape(-1, n_out))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _mm_nn(g2, weight, True).view(ctx.x_shape)
+            gx = (torch.mm(g2, _b16(weight)) if ctx.x_bf16 else _mm_nn(g2, weight, True)).view(ctx.x_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _wgrad(xb, g2, weight, ctx.has_bias, True)
-        return gx, gw, gb
+        return gx, gw, gb, None
 
 
-def linear(x, weight, bias=None):
-    """F.linear with the long-token weight-gradient kernel where it applies (and bf16 GEMM operands in DENSE_BF16 mode)."""
+def linear(x, weight, bias=None, out_bf16=False):
+    """F.linear with the long-token weight-gradient kernel where it applies (and bf16 GEMMs in DENSE_BF16 mode;
+    out_bf16 is honoured there only -- callers check `_dense_bf16(x, weight)` first)."""
     if weight.dim() == 2 and _dense_bf16(x, weight):
-        return LinearBF16.apply(x, weight, bias) if torch.is_grad_enabled() else _lin(x, weight, bias, True)
+        if torch.is_grad_enabled():
+            return LinearBF16.apply(x, weight, bias, out_bf16)
+        return _lin(x, weight, bias, True)
+    assert not out_bf16 and x.dtype == torch.float32, "bf16 boundary tensors exist only between dense-bf16 operators"
     if LINEAR_WGRAD_KERNEL and LinearLongTokens.supported(x, weight):
         return LinearLongTokens.apply(x, weight, bias)
     return torch.nn.functional.linear(x, weight, bias)

@@ -60,3 +60,39 @@ def test_mlp_helper_fused_equals_unfused():
     pm.FUSED_BN_RELU = True
     assert torch.allclose(outs[0][0], outs[1][0], atol=2e-5, rtol=1e-5)
     assert torch.allclose(outs[0][1], outs[1][1], atol=1e-8 + 2e-5 * outs[1][1].abs().max().item())
+
+
+@pytest.mark.parametrize("rows,c", [(7, 4), (4099, 64), (32768, 256), (1000, 512)])
+def test_dense_bf16_boundary_variants(rows, c):
+    """pda_bn_relu_{fwd,bwd}_mixed: bf16 tensors on the GEMM side (x, grad_y in; y, grad_x out), same arithmetic.  On
+    bf16-valued inputs: statistics, fp32 outputs and parameter gradients bit-identical to the fp32 entry points, bf16
+    outputs = the fp32 results rounded to nearest even."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(rows + c)
+    dev = "cuda"
+    xb = (torch.randn(rows, c, device=dev) * 1.3 + 0.2).bfloat16()
+    gyb = torch.randn(rows, c, device=dev).bfloat16()
+    g, b = torch.rand(c, device=dev) + 0.5, torch.randn(c, device=dev) * 0.3
+    scratch = torch.empty(ext.bn_relu_scratch_bytes(c), dtype=torch.uint8, device=dev)
+
+    def fwd(x, out_dtype):
+        rm, rv = torch.zeros(c, device=dev), torch.ones(c, device=dev)
+        y, st = torch.empty(rows, c, device=dev, dtype=out_dtype), torch.empty(2, c, device=dev)
+        ext.bn_relu_fwd(x, g, b, rm, rv, y, st, scratch, rows, c, 1e-5, 0.1)
+        return y, st, rm, rv
+    y0, st0, rm0, rv0 = fwd(xb.float(), torch.float32)
+    for x, od in ((xb, torch.float32), (xb, torch.bfloat16), (xb.float(), torch.bfloat16)):
+        y, st, rm, rv = fwd(x, od)
+        assert torch.equal(st, st0) and torch.equal(rm, rm0) and torch.equal(rv, rv0)
+        assert torch.equal(y, y0 if od == torch.float32 else y0.bfloat16())
+
+    def bwd(x, gy):
+        gx, gg, gb_ = torch.empty_like(x), torch.empty(c, device=dev), torch.empty(c, device=dev)
+        ext.bn_relu_bwd(x, gy, g, b, st0, gx, gg, gb_, scratch, rows, c)
+        return gx, gg, gb_
+    gx0, gg0, gb0 = bwd(xb.float(), gyb.float())
+    for x, gy in ((xb, gyb), (xb, gyb.float()), (xb.float(), gyb)):
+        gx, gg, gb_ = bwd(x, gy)
+        assert gx.dtype == x.dtype
+        assert torch.equal(gg, gg0) and torch.equal(gb_, gb0)
+        assert torch.equal(gx, gx0 if x.dtype == torch.float32 else gx0.bfloat16())
