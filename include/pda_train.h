@@ -87,6 +87,10 @@ int pda_layer_norm_bwd_mixed(const float *x, const float *grad_y, const void *gr
 int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_features);
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
+/* Dense-bf16 mode: the bias gradient alone, column sums of the bf16 gradient g (rows, cols) -> out (cols) fp32 (fixed
+ * summation order).  cols: multiple of 8, <= 2048; scratch: pda_colsum_scratch_bytes(cols) bytes. */
+int64_t pda_colsum_scratch_bytes(int cols);
+int pda_colsum_bf16(const uint16_t *g, float *out, void *scratch, int64_t rows, int cols, pda_stream_t stream);
 
 /* Token assembly of a PDA scale (MI355X extension; pointnet2_modules.py:879-922), point-major:
  * out (B,M,ns,4C) = [rppe (B,M,ns,C) | f * dscale | f | glob (B,M,C) broadcast over ns] with f = feats (B,N,C)

@@ -9,7 +9,12 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
+
+# Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
+# parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
+# copies, BatchNorm folded into convolutions) key on it next to the version counters.
+PARAM_EPOCH = [0]
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -56,6 +61,8 @@ SIGNATURES = {
     "pda_layer_norm_bwd_mixed": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_colsum_scratch_bytes": [_i],
+    "pda_colsum_bf16": [_vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_assemble_tokens_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_add_max_pool": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
@@ -110,6 +117,7 @@ def load():
     lib.pda_bn_relu_scratch_bytes.restype = ctypes.c_int64
     lib.pda_layer_norm_scratch_bytes.restype = ctypes.c_int64
     lib.pda_linear_wgrad_scratch_bytes.restype = ctypes.c_int64
+    lib.pda_colsum_scratch_bytes.restype = ctypes.c_int64
     lib.pda_densitynet_scratch_bytes.restype = ctypes.c_int64
     lib.pda_abi_version.restype = _i
     lib.pda_last_error.restype = ctypes.c_char_p

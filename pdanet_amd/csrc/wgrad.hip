@@ -262,3 +262,84 @@ PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_
                        grad_bias, S, nm, N);
     return pda::check_launch("pda_linear_wgrad");
 }
+
+// ---- column sums of a bf16 (rows, cols) matrix: the bias gradient in dense-bf16 mode ---------------------------
+// (fp32 mode gets it from wgrad_kernel on the way.)  Two deterministic stages like everything else here: per-block fp32
+// partials over a strided set of rows (16-byte loads of 8 bf16 per lane), then a fixed-order double sum per column.
+namespace pda {
+
+constexpr int CS_BLOCKS = 512;
+
+__global__ __launch_bounds__(256) void colsum_bf16_kernel(const bf16_t* __restrict__ g, float* __restrict__ partial, int64_t rows,
+                                                          int cols, int nv, int rpb) {
+    __shared__ float lds[256 * 8];
+    const int tid = threadIdx.x;
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const int v = tid % nv, r0 = tid / nv;
+    if (tid < nv * rpb) {
+        for (int64_t r = (int64_t)blockIdx.x * rpb + r0; r < rows; r += (int64_t)gridDim.x * rpb) {
+            const uint4 u = *reinterpret_cast<const uint4*>(g + r * cols + 8 * v);
+            acc[0] += __uint_as_float(u.x << 16); acc[1] += __uint_as_float(u.x & 0xffff0000u);
+            acc[2] += __uint_as_float(u.y << 16); acc[3] += __uint_as_float(u.y & 0xffff0000u);
+            acc[4] += __uint_as_float(u.z << 16); acc[5] += __uint_as_float(u.z & 0xffff0000u);
+            acc[6] += __uint_as_float(u.w << 16); acc[7] += __uint_as_float(u.w & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) lds[tid * 8 + k] = acc[k];
+    __syncthreads();
+    if (tid < nv) {
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rpb; ++r)
+#pragma unroll
+            for (int k = 0; k < 8; ++k) s[k] += lds[(r * nv + tid) * 8 + k];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) partial[(size_t)blockIdx.x * cols + 8 * tid + k] = s[k];
+    }
+}
+
+// 16 columns x 16 slices of the per-block partials per workgroup
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ partial, int nblocks, int cols,
+                                                           float* __restrict__ out) {
+    __shared__ double red[16][16];
+    const int cl = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a = 0.0;
+    if (c < cols) {
+        float va[8];
+        for (int k0 = part; k0 < nblocks; k0 += 16 * 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + 16 * u;
+                va[u] = k < nblocks ? partial[(size_t)k * cols + c] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += (double)va[u];
+        }
+    }
+    red[part][cl] = a;
+    __syncthreads();
+    if (part != 0 || c >= cols) return;
+    double s = 0.0;
+#pragma unroll
+    for (int p = 0; p < 16; ++p) s += red[p][cl];
+    out[c] = (float)s;
+}
+
+}  // namespace pda
+
+PDA_API int64_t pda_colsum_scratch_bytes(int cols) { return (int64_t)pda::CS_BLOCKS * (cols > 0 ? cols : 0) * (int64_t)sizeof(float); }
+
+PDA_API int pda_colsum_bf16(const uint16_t* g, float* out, void* scratch, int64_t rows, int cols, pda_stream_t stream) {
+    PDA_REQUIRE(rows >= 1 && cols >= 8 && cols <= 2048 && (cols & 7) == 0, "pda_colsum_bf16: rows=%lld cols=%d (cols: multiple of 8, <= 2048)",
+                (long long)rows, cols);
+    PDA_REQUIRE(g && out && scratch, "pda_colsum_bf16: null pointer");
+    PDA_REQUIRE(((uintptr_t)g & 15) == 0, "pda_colsum_bf16: g must be 16-byte aligned");
+    const int nv = cols / 8, rpb = 256 / nv;
+    const int64_t steps = pda::divup64(rows, (int64_t)rpb * 8);
+    const int grid = (int)(steps < pda::CS_BLOCKS ? steps : pda::CS_BLOCKS);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(pda::colsum_bf16_kernel, dim3(grid), dim3(256), 0, st, g, (float*)scratch, rows, cols, nv, rpb);
+    hipLaunchKernelGGL(pda::colsum_final_kernel, dim3(pda::divup(cols, 16)), dim3(256), 0, st, (const float*)scratch, grid, cols, out);
+    return pda::check_launch("pda_colsum_bf16");
+}

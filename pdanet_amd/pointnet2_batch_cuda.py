@@ -315,6 +315,15 @@ def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_f
     return 1
 
 
+def colsum_bf16(g, out, rows, cols):
+    """MI355X extension: out (cols) fp32 = column sums of the bf16 matrix g (rows, cols): the bias gradient in dense-bf16
+    mode (csrc/wgrad.hip; fixed summation order)."""
+    _numel_ok(g, rows * cols, "g"); _numel_ok(out, cols, "out")
+    scratch = torch.empty((int(_lib.load().pda_colsum_scratch_bytes(cols)),), dtype=torch.uint8, device=g.device)
+    _call("pda_colsum_bf16", g, _chk(g, "g", torch.bfloat16), _chk(out, "out", F32), _chk(scratch, "scratch", torch.uint8), rows, cols)
+    return 1
+
+
 def densitynet_sizes():
     lib = _lib.load()
     return int(lib.pda_densitynet_param_count()), int(lib.pda_densitynet_scratch_bytes())

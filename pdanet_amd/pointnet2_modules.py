@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import _lib
 from . import pointnet2_utils
 
 
@@ -108,7 +109,7 @@ def _folded_conv_bn(conv, bn):
     s = gamma / sqrt(running_var + eps).  Cached on the BN module, keyed on the version counters of every tensor
     involved (an optimizer step, a load_state_dict or a training-mode forward invalidates it)."""
     tensors = (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var)
-    key = tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
+    key = (_lib.PARAM_EPOCH[0],) + tuple(None if t is None else (t._version, t.data_ptr()) for t in tensors)
     cache = bn.__dict__.get("_pda_folded")
     if cache is None or cache[0] != key:
         with torch.no_grad():

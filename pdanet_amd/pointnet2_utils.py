@@ -9,12 +9,14 @@ the kernels underneath are the hand-written gfx950 ones reached through the C AB
     so the ops work under side streams and hipGraph capture;
   * the grouper modules use one multi-radius ball query when asked for several scales.
 """
+import weakref
 from typing import List, Tuple
 
 import torch
 import torch.nn as nn
 from torch.autograd import Function
 
+from . import _lib
 from . import pointnet2_batch_cuda as pointnet2
 
 # Under torch.autocast the dense layers may run in bf16; the point operators always compute in
@@ -474,17 +476,35 @@ def _b16(t):
     return t if t.dtype == torch.bfloat16 else t.to(torch.bfloat16)
 
 
+_B16_PARAMS = {}
+
+
+def _b16p(p):
+    """bf16 copy of a parameter (weight / bias), cached until the parameter is written again (its version counter moves:
+    optimizer step, load_state_dict) -- a step uses each weight in 2-3 GEMMs, and each cast is a launch."""
+    if p.dtype == torch.bfloat16:
+        return p
+    key = id(p)
+    stamp = (p._version, p.data_ptr(), _lib.PARAM_EPOCH[0])
+    hit = _B16_PARAMS.get(key)
+    if hit is not None and hit[0] == stamp and hit[1]() is p:
+        return hit[2]
+    pb = p.detach().to(torch.bfloat16)
+    _B16_PARAMS[key] = (stamp, weakref.ref(p, lambda _r, k=key: _B16_PARAMS.pop(k, None)), pb)
+    return pb
+
+
 def _mm_nt(x2d, w, bf16):
     """x2d (T, in) @ w (out, in)^T -> (T, out) fp32."""
     if bf16:
-        return torch.mm(_b16(x2d), _b16(w).t(), out_dtype=torch.float32)
+        return torch.mm(_b16(x2d), _b16p(w).t(), out_dtype=torch.float32)
     return x2d.mm(w.t())
 
 
 def _mm_nn(g2d, w, bf16, acc=None):
     """g2d (T, out) @ w (out, in) -> (T, in) fp32; acc: a (T, in) fp32 tensor OWNED by the caller to accumulate into."""
     if bf16:
-        gb, wb = _b16(g2d), _b16(w)
+        gb, wb = _b16(g2d), _b16p(w)
         if acc is not None:
             return torch.addmm(acc, gb, wb, out_dtype=torch.float32)
         return torch.mm(gb, wb, out_dtype=torch.float32)
@@ -517,8 +537,8 @@ class LinearBF16(Function):
     def forward(ctx, x, weight, bias, out_bf16=False):
         xb = _b16(x.reshape(-1, x.shape[-1]))
         if out_bf16:
-            wb = _b16(weight)
-            y = torch.mm(xb, wb.t()) if bias is None else torch.addmm(_b16(bias), xb, wb.t())
+            wb = _b16p(weight)
+            y = torch.mm(xb, wb.t()) if bias is None else torch.addmm(_b16p(bias), xb, wb.t())
         else:
             y = _mm_nt(xb, weight, True)
             if bias is not None:
@@ -534,7 +554,7 @@ class LinearBF16(Function):
         g2 = _b16(grad_out.reshape(-1, n_out))
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = (torch.mm(g2, _b16(weight)) if ctx.x_bf16 else _mm_nn(g2, weight, True)).view(ctx.x_shape)
+            gx = (torch.mm(g2, _b16p(weight)) if ctx.x_bf16 else _mm_nn(g2, weight, True)).view(ctx.x_shape)
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             gw, gb = _wgrad(xb, g2, weight, ctx.has_bias, True)
         return gx, gw, gb, None
@@ -572,7 +592,13 @@ def _wgrad_bf16(xb, gb, want_bias):
         gw = torch.bmm(gb.view(S, T // S, n_out).transpose(1, 2), xb.view(S, T // S, n_in), out_dtype=torch.float32).sum(0)
     else:
         gw = torch.mm(gb.t(), xb, out_dtype=torch.float32)
-    return gw, (gb.sum(0, dtype=torch.float32) if want_bias else None)
+    if not want_bias:
+        return gw, None
+    if n_out % 8 == 0 and n_out <= 2048 and gb.is_contiguous():
+        gbias = torch.empty((n_out,), dtype=torch.float32, device=gb.device)
+        pointnet2.colsum_bf16(gb, gbias, T, n_out)
+        return gw, gbias
+    return gw, gb.sum(0, dtype=torch.float32)
 
 
 def _wgrad(x2d, g2d, weight, want_bias, bf16=False):
@@ -621,14 +647,14 @@ class TransformerBlock(Function):
             b16 = dict(dtype=torch.bfloat16, device=dev)
             src1_s, src2_s = torch.empty((T, D), **b16), torch.empty((T, D), **b16)
             pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1, y_bf16=src1_s)
-            qkv = torch.addmm(_b16(in_b), src1_s, _b16(in_w).t())
+            qkv = torch.addmm(_b16p(in_b), src1_s, _b16p(in_w).t())
             a_s = torch.empty((T, D), **b16)
             pointnet2.group_attention_fwd(qkv, a_s, lse, G, S, heads, hd)
-            proj = torch.addmm(_b16(out_b), a_s, _b16(out_w).t())
+            proj = torch.addmm(_b16p(out_b), a_s, _b16p(out_w).t())
             pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2, y_bf16=src2_s)
             del proj
-            h = h_s = torch._addmm_activation(_b16(b1), src2_s, _b16(w1).t())      # relu(src2 W1^T + b1)
-            ffn = torch.addmm(_b16(b2), h, _b16(w2).t()).view(G, S, D)
+            h = h_s = torch._addmm_activation(_b16p(b1), src2_s, _b16p(w1).t())      # relu(src2 W1^T + b1)
+            ffn = torch.addmm(_b16p(b2), h, _b16p(w2).t()).view(G, S, D)
         else:
             pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
             qkv = torch.nn.functional.linear(src1, in_w, in_b)
@@ -671,7 +697,7 @@ class TransformerBlock(Function):
             dy2 = dy.contiguous().view(T, D)
             dy_g = _b16(dy2) if bf16 else dy2
         # y = src2 + h W2^T + b2
-        d_h = torch.mm(dy_g, _b16(w2)) if bf16 else dy_g.mm(w2)
+        d_h = torch.mm(dy_g, _b16p(w2)) if bf16 else dy_g.mm(w2)
         if bf16 and ctx.pool:   # the scattered gradient's column sums are those of the (G, D) tensor it was scattered from
             gw2, gb2 = _wgrad(h_s, dy_g, w2, False, True)[0], dy.sum(0)
         else:
@@ -681,7 +707,7 @@ class TransformerBlock(Function):
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
         gw1, gb1 = _wgrad(src2_s, d_h, w1, True, bf16)
-        d_lin1 = torch.mm(d_h, _b16(w1)) if bf16 else d_h.mm(w1)
+        d_lin1 = torch.mm(d_h, _b16p(w1)) if bf16 else d_h.mm(w1)
         del d_h
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
         d_s = torch.empty((T, D), **f32)
@@ -690,7 +716,7 @@ class TransformerBlock(Function):
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1, grad_x_bf16=ds_g if bf16 else None)
         del d_lin1
-        d_a = torch.mm(ds_g, _b16(out_w)) if bf16 else d_s.mm(out_w)
+        d_a = torch.mm(ds_g, _b16p(out_w)) if bf16 else d_s.mm(out_w)
         gwo, gbo = _wgrad(a_s, ds_g, out_w, True, bf16)
         del ds_g
         dqkv = torch.empty_like(qkv)

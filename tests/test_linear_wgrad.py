@@ -40,3 +40,18 @@ def test_dispatch_threshold_and_views():
     ref = torch.autograd.grad(F.linear(x, conv.weight.flatten(1)).square().sum(), conv.weight)[0]
     assert gw.shape == conv.weight.shape
     assert (gw - ref).abs().max().item() < 3e-5 * ref.abs().max().item()
+
+
+@pytest.mark.parametrize("rows,cols", [(1, 8), (1000, 24), (65536, 768), (262144, 128), (4099, 1536), (33, 2048)])
+def test_colsum_bf16(rows, cols):
+    """pda_colsum_bf16 (dense-bf16 bias gradient) against a float64 column sum of the same bf16 values."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    torch.manual_seed(rows + cols)
+    g = (torch.randn(rows, cols, device="cuda") * 0.5 + 0.1).bfloat16()
+    out = torch.empty(cols, device="cuda")
+    ext.colsum_bf16(g, out, rows, cols)
+    ref = g.double().sum(0)
+    assert (out.double() - ref).abs().max().item() <= 2e-6 * g.double().abs().sum(0).max().item() + 1e-6
+    out2 = torch.empty(cols, device="cuda")
+    ext.colsum_bf16(g, out2, rows, cols)
+    assert torch.equal(out, out2)            # fixed summation order

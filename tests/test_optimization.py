@@ -117,3 +117,34 @@ def test_gradients_accumulate_into_the_flat_buffer(gold):
     assert float(o.flat_g.abs().sum()) > 0
     o.zero_grad()
     assert float(model.head.weight.grad.abs().sum()) == 0
+
+
+@pytest.mark.gpu
+def test_derived_tensor_caches_follow_the_raw_pointer_optimizer():
+    """FlatAdamOneCycle writes parameters through a raw pointer (version counters do not move): the cached bf16 weight
+    copies (dense-bf16 mode) and the BatchNorm-folded inference weights must still be refreshed after a step."""
+    import torch.nn as nn
+    from pdanet_amd import optimization, pointnet2_utils as pu, pointnet2_modules as pm
+    torch.manual_seed(0)
+    model = nn.Sequential(nn.Conv2d(8, 16, 1, bias=False), nn.BatchNorm2d(16), nn.ReLU()).cuda()
+    opt = optimization.FlatAdamOneCycle(model, wd=0.01, lr=1e-2)
+    conv, bn = model[0], model[1]
+    wb0 = pu._b16p(conv.weight).clone()
+    assert pu._b16p(conv.weight) is pu._b16p(conv.weight)          # cached while nothing changes
+    model.eval()
+    with torch.no_grad():
+        w0 = pm._folded_conv_bn(conv, bn)[0].clone()
+    model.train()
+    x = torch.randn(4, 8, 5, 5, device="cuda")
+    opt.zero_grad()
+    model(x).square().mean().backward()
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(pu._b16p(conv.weight), wb0)
+    assert torch.equal(pu._b16p(conv.weight), conv.weight.detach().bfloat16())
+    model.eval()
+    with torch.no_grad():
+        w1, b1 = pm._folded_conv_bn(conv, bn)
+        s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
+        assert not torch.equal(w1, w0)
+        assert torch.allclose(w1, conv.weight.flatten(1) * s[:, None])
