@@ -663,7 +663,7 @@ class TransformerBlock(Function):
             proj = torch.nn.functional.linear(a, out_w, out_b)
             pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
             del proj
-            h = torch.relu_(torch.nn.functional.linear(src2, w1, b1))
+            h = torch._addmm_activation(b1, src2.view(T, D), w1.t()).view(G, S, -1)     # relu(src2 W1^T + b1), epilogue ReLU
             ffn = torch.nn.functional.linear(h, w2, b2)
             src1_s, a_s, src2_s, h_s = src1.view(T, D), a.view(T, D), src2.view(T, D), h.view(T, -1)
         if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
