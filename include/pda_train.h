@@ -52,6 +52,18 @@ int pda_bn_relu_fwd_mixed(const void *x, int x_is_bf16, const float *gamma, cons
 int pda_bn_relu_bwd_mixed(const void *x, int x_is_bf16, const void *grad_y, int grad_y_is_bf16, const float *gamma,
                           const float *beta, const float *mean_invstd, void *grad_x, float *grad_gamma,
                           float *grad_beta, void *scratch, int64_t rows, int c, pda_stream_t stream);
+/* The last [BN -> ReLU] of a set-abstraction MLP together with the max-pool over the group's samples that follows it
+ * (pointnet2_modules.py:1657-1670): x (groups*ns, C), row = group*ns + sample (fp32, or bf16 when x_is_bf16) ->
+ * out (groups, C) = max over the ns rows of relu(bn(x)), arg (groups, C) uint8 = first row attaining it; the (rows, C)
+ * activation is never written.  Backward takes grad_out (groups, C) and arg: the dense (rows, C) gradient is generated on
+ * the fly inside the two BN-backward passes, never stored.  grad_x has the element type of x.  ns <= 255. */
+int pda_bn_relu_max_pool_fwd(const void *x, int x_is_bf16, const float *gamma, const float *beta, float *running_mean,
+                             float *running_var, float *out, uint8_t *arg, float *mean_invstd, void *scratch,
+                             int64_t groups, int ns, int c, float eps, float momentum, pda_stream_t stream);
+int pda_bn_relu_max_pool_bwd(const void *x, int x_is_bf16, const float *grad_out, const uint8_t *arg,
+                             const float *gamma, const float *beta, const float *mean_invstd, void *grad_x,
+                             float *grad_gamma, float *grad_beta, void *scratch, int64_t groups, int ns, int c,
+                             pda_stream_t stream);
 
 /* ---- LayerNorm over the last dimension with optional fused residual add (MI355X extension) ----------
  * nn.LayerNorm(D) of TransformerEncoderLayerPreNorm (PointFormer.py:17-18,29,33): x (rows, D) [+ residual

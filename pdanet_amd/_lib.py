@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -53,6 +53,8 @@ SIGNATURES = {
     "pda_bn_relu_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
     "pda_bn_relu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],    "pda_bn_relu_fwd_mixed": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
     "pda_bn_relu_bwd_mixed": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
+    "pda_bn_relu_max_pool_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _f, _f, _vp],
+    "pda_bn_relu_max_pool_bwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
 
     "pda_layer_norm_scratch_bytes": [_i],
     "pda_layer_norm_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],

@@ -18,7 +18,19 @@ constexpr int BN_BLOCKS = 512;
 struct BnShape {
     int64_t rows;
     int c, cg, rpb;  // cg = C/4 thread columns; rpb = rows per block step = 256 / cg (>= 1)
+    int ns;          // pooled forms: rows per group (the max-pool runs over ns consecutive rows)
 };
+
+// Pooled backward: the incoming gradient is that of out[g][c] = max over the ns rows of group g of y; it reaches row
+// g*ns + arg[g][c] only.  The dense (rows, C) gradient is never built: it is generated on the fly from (gout, arg).
+__device__ __forceinline__ float4 pooled_grad(const float* __restrict__ gout, const uint8_t* __restrict__ arg, int64_t r,
+                                              int col, const BnShape& s) {
+    const int64_t g = r / s.ns;
+    const int t = (int)(r - g * s.ns);
+    const float4 v = reinterpret_cast<const float4*>(gout)[g * s.cg + col];
+    const uchar4 k = reinterpret_cast<const uchar4*>(arg)[g * s.cg + col];
+    return make_float4(k.x == t ? v.x : 0.f, k.y == t ? v.y : 0.f, k.z == t ? v.z : 0.f, k.w == t ? v.w : 0.f);
+}
 
 __device__ __forceinline__ void block_reduce_cols(double (&a)[4], double (&b)[4], double* lds, int cg, int rpb, double* out_a,
                                                   double* out_b) {
@@ -42,10 +54,11 @@ __device__ __forceinline__ void block_reduce_cols(double (&a)[4], double (&b)[4]
 // BWD == false: partial[blk][0][c] = sum x, [1][c] = sum x^2
 // BWD == true : with dyh = dy * [(x - mean) * invstd * gamma + beta > 0]: [0][c] = sum dyh, [1][c] = sum dyh * xhat
 // TX / TD: element types of x and dy -- float, or bf16 where the tensor is the output of a bf16 GEMM (dense-bf16 mode)
-template <bool BWD, typename TX, typename TD>
+template <bool BWD, typename TX, typename TD, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const TX* __restrict__ x, const TD* __restrict__ dy,
                                                         const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
-                                                        const float* __restrict__ beta, double* __restrict__ partial, BnShape s) {
+                                                        const float* __restrict__ beta, double* __restrict__ partial, BnShape s,
+                                                        const uint8_t* __restrict__ arg = nullptr) {
     __shared__ double lds[2 * 256 * 4];
     const int tid = threadIdx.x;
     double a[4] = {0, 0, 0, 0}, b[4] = {0, 0, 0, 0};
@@ -64,7 +77,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TX* __restrict__ x
                 a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
                 b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
             } else {
-                const float4 d = load4(dy + r * s.c + 4 * col);
+                float4 d;
+                if constexpr (POOL) d = pooled_grad(reinterpret_cast<const float*>(dy), arg, r, col, s);
+                else d = load4(dy + r * s.c + 4 * col);
                 const float xh[4] = {(v.x - mu.x) * is.x, (v.y - mu.y) * is.y, (v.z - mu.z) * is.z, (v.w - mu.w) * is.w};
                 const float gg[4] = {g.x, g.y, g.z, g.w}, bb[4] = {be.x, be.y, be.z, be.w}, dd[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
@@ -144,11 +159,11 @@ __global__ __launch_bounds__(512) void bn_finalize_bwd_kernel(const double* __re
 
 // BWD == false: y = relu((x - mean) * invstd * gamma + beta)
 // BWD == true : dx = gamma * invstd * (dyh - mean(dyh) - xhat * mean(dyh * xhat))
-template <bool BWD, typename TX, typename TD, typename TO>
+template <bool BWD, typename TX, typename TD, typename TO, bool POOL = false>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x, const TD* __restrict__ dy,
                                                        const float* __restrict__ mean_invstd, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const float* __restrict__ sums,
-                                                       TO* __restrict__ out, BnShape s) {
+                                                       TO* __restrict__ out, BnShape s, const uint8_t* __restrict__ arg = nullptr) {
     const int tid = threadIdx.x;
     const int col = tid % s.cg, r0 = tid / s.cg;
     const float4 mu = reinterpret_cast<const float4*>(mean_invstd)[col], is = reinterpret_cast<const float4*>(mean_invstd + s.c)[col];
@@ -165,7 +180,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = fmaxf((xv[k] - muv[k]) * isv[k] * gv[k] + bv[k], 0.f);
         } else {
-            const float4 d = load4(dy + r * s.c + 4 * col);
+            float4 d;
+            if constexpr (POOL) d = pooled_grad(reinterpret_cast<const float*>(dy), arg, r, col, s);
+            else d = load4(dy + r * s.c + 4 * col);
             const float dv[4] = {d.x, d.y, d.z, d.w};
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -178,10 +195,39 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
     }
 }
 
+// forward with the max-pool fused in: thread = (group, 4-channel column); y = relu(bn(x)) is never written, out (groups, C)
+// = max over the group's ns rows, arg = the first row that attains it
+template <typename TX>
+__global__ __launch_bounds__(256) void bn_apply_pool_kernel(const TX* __restrict__ x, const float* __restrict__ mean_invstd,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ out, uint8_t* __restrict__ arg, int64_t groups,
+                                                            BnShape s) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= groups * s.cg) return;
+    const int64_t g = e / s.cg;
+    const int col = (int)(e - g * s.cg);
+    const float4 mu = reinterpret_cast<const float4*>(mean_invstd)[col], is = reinterpret_cast<const float4*>(mean_invstd + s.c)[col];
+    const float4 gm = reinterpret_cast<const float4*>(gamma)[col], be = reinterpret_cast<const float4*>(beta)[col];
+    float4 best = make_float4(-1.f, -1.f, -1.f, -1.f);     // y >= 0: the first row always wins against -1
+    uchar4 bi = make_uchar4(0, 0, 0, 0);
+    const TX* px = x + (size_t)g * s.ns * s.c + 4 * col;
+    for (int t = 0; t < s.ns; ++t) {
+        const float4 v = load4(px + (size_t)t * s.c);
+        const float y0 = fmaxf((v.x - mu.x) * is.x * gm.x + be.x, 0.f), y1 = fmaxf((v.y - mu.y) * is.y * gm.y + be.y, 0.f);
+        const float y2 = fmaxf((v.z - mu.z) * is.z * gm.z + be.z, 0.f), y3 = fmaxf((v.w - mu.w) * is.w * gm.w + be.w, 0.f);
+        if (y0 > best.x) { best.x = y0; bi.x = (uint8_t)t; }
+        if (y1 > best.y) { best.y = y1; bi.y = (uint8_t)t; }
+        if (y2 > best.z) { best.z = y2; bi.z = (uint8_t)t; }
+        if (y3 > best.w) { best.w = y3; bi.w = (uint8_t)t; }
+    }
+    reinterpret_cast<float4*>(out)[e] = best;
+    reinterpret_cast<uchar4*>(arg)[e] = bi;
+}
+
 static int bn_shape(int64_t rows, int c, BnShape& s, const char* what) {
     PDA_REQUIRE(rows >= 1, "%s: rows = %lld", what, (long long)rows);
     PDA_REQUIRE(c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "%s: C = %d is not a power of two in [4, 1024]", what, c);
-    s.rows = rows; s.c = c; s.cg = c / 4; s.rpb = 256 / s.cg;
+    s.rows = rows; s.c = c; s.cg = c / 4; s.rpb = 256 / s.cg; s.ns = 1;
     return PDA_OK;
 }
 
@@ -239,6 +285,50 @@ static int launch_bn_relu_bwd(const TX* x, const TD* grad_y, const float* gamma,
     return check_launch(what);
 }
 
+template <typename TX>
+static int launch_bn_relu_pool_fwd(const TX* x, const float* gamma, const float* beta, float* running_mean, float* running_var, float* out,
+                                   uint8_t* arg, float* mean_invstd, void* scratch, int64_t groups, int ns, int c, float eps,
+                                   float momentum, hipStream_t st, const char* what) {
+    PDA_REQUIRE(groups >= 1 && ns >= 1 && ns <= 255, "%s: groups=%lld ns=%d (1..255)", what, (long long)groups, ns);
+    BnShape s;
+    if (int rc = bn_shape(groups * ns, c, s, what)) return rc;
+    s.ns = ns;
+    PDA_REQUIRE(x && gamma && beta && out && arg && mean_invstd && scratch, "%s: null pointer", what);
+    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running_mean/var must come together", what);
+    PDA_REQUIRE(bn_aligned(x) && (((uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0 &&
+                    ((uintptr_t)arg & 3) == 0, "%s: alignment", what);
+    const int grid = bn_grid(s);
+    hipLaunchKernelGGL((bn_reduce_kernel<false, TX, float>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (double*)scratch, s, (const uint8_t*)nullptr);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, s.rows, eps, momentum,
+                       mean_invstd, running_mean, running_var);
+    hipLaunchKernelGGL(bn_apply_pool_kernel<TX>, dim3((unsigned)divup64(groups * s.cg, 256)), dim3(256), 0, st, x, mean_invstd, gamma, beta, out,
+                       arg, groups, s);
+    return check_launch(what);
+}
+
+template <typename TX>
+static int launch_bn_relu_pool_bwd(const TX* x, const float* grad_out, const uint8_t* arg, const float* gamma, const float* beta,
+                                   const float* mean_invstd, TX* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t groups,
+                                   int ns, int c, hipStream_t st, const char* what) {
+    PDA_REQUIRE(groups >= 1 && ns >= 1 && ns <= 255, "%s: groups=%lld ns=%d (1..255)", what, (long long)groups, ns);
+    BnShape s;
+    if (int rc = bn_shape(groups * ns, c, s, what)) return rc;
+    s.ns = ns;
+    PDA_REQUIRE(x && grad_out && arg && gamma && beta && mean_invstd && grad_x && grad_gamma && grad_beta && scratch, "%s: null pointer", what);
+    PDA_REQUIRE(bn_aligned(x) && bn_aligned(grad_x) && (((uintptr_t)grad_out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0 &&
+                    ((uintptr_t)arg & 3) == 0, "%s: alignment", what);
+    const int grid = bn_grid(s);
+    float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)BN_BLOCKS * 2 * c);
+    hipLaunchKernelGGL((bn_reduce_kernel<true, TX, float, true>), dim3(grid), dim3(256), 0, st, x, grad_out, mean_invstd, gamma, beta,
+                       (double*)scratch, s, arg);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, s.rows, grad_gamma, grad_beta,
+                       sums);
+    hipLaunchKernelGGL((bn_apply_kernel<true, TX, float, TX, true>), dim3(grid), dim3(256), 0, st, x, grad_out, mean_invstd, gamma, beta, sums,
+                       grad_x, s, arg);
+    return check_launch(what);
+}
+
 }  // namespace pda
 
 PDA_API int pda_bn_relu_fwd(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
@@ -277,4 +367,26 @@ PDA_API int pda_bn_relu_bwd_mixed(const void* x, int x_is_bf16, const void* grad
     if (x_is_bf16) return grad_y_is_bf16 ? PDA_BN_BWD(bf16_t, bf16_t) : PDA_BN_BWD(bf16_t, float);
     return grad_y_is_bf16 ? PDA_BN_BWD(float, bf16_t) : PDA_BN_BWD(float, float);
 #undef PDA_BN_BWD
+}
+
+PDA_API int pda_bn_relu_max_pool_fwd(const void* x, int x_is_bf16, const float* gamma, const float* beta, float* running_mean,
+                                     float* running_var, float* out, uint8_t* arg, float* mean_invstd, void* scratch, int64_t groups,
+                                     int ns, int c, float eps, float momentum, pda_stream_t stream) {
+    const char* what = "pda_bn_relu_max_pool_fwd";
+    if (x_is_bf16)
+        return pda::launch_bn_relu_pool_fwd<pda::bf16_t>((const pda::bf16_t*)x, gamma, beta, running_mean, running_var, out, arg, mean_invstd,
+                                                         scratch, groups, ns, c, eps, momentum, (hipStream_t)stream, what);
+    return pda::launch_bn_relu_pool_fwd<float>((const float*)x, gamma, beta, running_mean, running_var, out, arg, mean_invstd, scratch, groups,
+                                               ns, c, eps, momentum, (hipStream_t)stream, what);
+}
+
+PDA_API int pda_bn_relu_max_pool_bwd(const void* x, int x_is_bf16, const float* grad_out, const uint8_t* arg, const float* gamma,
+                                     const float* beta, const float* mean_invstd, void* grad_x, float* grad_gamma, float* grad_beta,
+                                     void* scratch, int64_t groups, int ns, int c, pda_stream_t stream) {
+    const char* what = "pda_bn_relu_max_pool_bwd";
+    if (x_is_bf16)
+        return pda::launch_bn_relu_pool_bwd<pda::bf16_t>((const pda::bf16_t*)x, grad_out, arg, gamma, beta, mean_invstd, (pda::bf16_t*)grad_x,
+                                                         grad_gamma, grad_beta, scratch, groups, ns, c, (hipStream_t)stream, what);
+    return pda::launch_bn_relu_pool_bwd<float>((const float*)x, grad_out, arg, gamma, beta, mean_invstd, (float*)grad_x, grad_gamma, grad_beta,
+                                               scratch, groups, ns, c, (hipStream_t)stream, what);
 }

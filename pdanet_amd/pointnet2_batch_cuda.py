@@ -253,6 +253,28 @@ def bn_relu_bwd(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_be
     return 1
 
 
+def bn_relu_max_pool_fwd(x, gamma, beta, running_mean, running_var, out, arg, mean_invstd, scratch, groups, ns, c, eps, momentum):
+    """MI355X extension: relu(bn(x)) (training mode) + max over the ns rows of each group, y never written (csrc/bn_relu.hip)."""
+    _numel_ok(x, groups * ns * c, "x"); _numel_ok(out, groups * c, "out"); _numel_ok(arg, groups * c, "arg"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
+    rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
+    rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    xp, xb = _io(x, "x")
+    _call("pda_bn_relu_max_pool_fwd", x, xp, xb, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv, _chk(out, "out", F32),
+          _chk(arg, "arg", torch.uint8), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), groups, ns, c,
+          float(eps), float(momentum))
+    return 1
+
+
+def bn_relu_max_pool_bwd(x, grad_out, arg, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, groups, ns, c):
+    _numel_ok(x, groups * ns * c, "x"); _numel_ok(grad_out, groups * c, "grad_out"); _numel_ok(arg, groups * c, "arg")
+    _numel_ok(grad_x, groups * ns * c, "grad_x")
+    xp, xb = _io(x, "x")
+    _call("pda_bn_relu_max_pool_bwd", x, xp, xb, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8), _chk(gamma, "gamma", F32),
+          _chk(beta, "beta", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", x.dtype), _chk(grad_gamma, "grad_gamma", F32),
+          _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), groups, ns, c)
+    return 1
+
+
 def layer_norm_scratch_bytes(d):
     return int(_lib.load().pda_layer_norm_scratch_bytes(int(d)))
 

@@ -136,10 +136,15 @@ def _linear_relu(x, w, b):
     return torch.relu_(pointnet2_utils.linear(x, w, b))
 
 
-def _mlp_lastdim(layers, x):
-    """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x."""
+FUSED_BN_RELU_MAX_POOL = True   # the last BN+ReLU of a grouped MLP and the max over nsample as one autograd node
+
+
+def _mlp_lastdim(layers, x, pool=False):
+    """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x; pool=True: followed by the max over
+    dim -2 (the nsample axis of a grouped tensor), fused into the last BN+ReLU in training mode."""
     layers = list(layers)
     skip = 0
+    pooled = False
     for k, m in enumerate(layers):
         if skip:
             skip -= 1
@@ -164,7 +169,12 @@ def _mlp_lastdim(layers, x):
                 after = layers[k + 2] if k + 2 < len(layers) else None
                 out_b = (x.dtype == torch.bfloat16 and isinstance(after, (nn.Conv2d, nn.Conv1d))
                          and pointnet2_utils._dense_bf16(x, after.weight.flatten(1)))
-                x = _bn_relu_lastdim(m, x, out_b)
+                if (pool and k + 2 == len(layers) and FUSED_BN_RELU and FUSED_BN_RELU_MAX_POOL
+                        and pointnet2_utils.BatchNormReLUMaxPool.supported(x, m)):
+                    x = pointnet2_utils.batch_norm_relu_max_pool(m, x)
+                    pooled = True
+                else:
+                    x = _bn_relu_lastdim(m, x, out_b)
                 skip = 1
             else:
                 x = _bn_lastdim(m, x)
@@ -172,6 +182,8 @@ def _mlp_lastdim(layers, x):
             x = F.relu(x)
         else:
             raise NotImplementedError(type(m))
+    if pool and not pooled:
+        x = x.max(dim=-2)[0]
     return x
 
 
@@ -398,7 +410,7 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                     g = pointnet2_utils.group_rows(xyz, idxs[i]) - new_xyz.unsqueeze(2)
                     if feats_pm is not None:
                         g = torch.cat([g, pointnet2_utils.group_rows(feats_pm, idxs[i])], dim=-1)
-                    g = _mlp_lastdim(self.mlps[i], g).max(dim=2)[0]          # (B, M, mlp[-1])
+                    g = _mlp_lastdim(self.mlps[i], g, pool=True)              # (B, M, mlp[-1]): MLP + max over nsample
                     new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
                     continue
                 if plain_ball:

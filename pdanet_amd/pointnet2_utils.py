@@ -288,6 +288,47 @@ class BatchNormReLU(Function):
         return grad_x, gw, gb, None, None, None, None, None
 
 
+class BatchNormReLUMaxPool(Function):
+    """MI355X extension: relu(bn(x)) in training mode followed by the max over dim -2 (the nsample axis of a grouped
+    (..., nsample, C) tensor), as one autograd node: the activation and the dense gradient of the max-pool are never
+    materialised (csrc/bn_relu.hip, pda_bn_relu_max_pool_{fwd,bwd})."""
+
+    @staticmethod
+    def supported(x, bn):
+        return BatchNormReLU.supported(x, bn) and x.dim() >= 3 and 1 <= x.shape[-2] <= 255
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum):
+        x = x.contiguous()
+        ns, c = x.shape[-2], x.shape[-1]
+        groups = x.numel() // (ns * c)
+        out = torch.empty(x.shape[:-2] + (c,), dtype=torch.float32, device=x.device)
+        arg = torch.empty(x.shape[:-2] + (c,), dtype=torch.uint8, device=x.device)
+        stats = torch.empty((2, c), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_max_pool_fwd(x, weight, bias, running_mean, running_var, out, arg, stats, scratch, groups, ns, c, eps, momentum)
+        ctx.save_for_backward(x, weight, bias, stats, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x, weight, bias, stats, arg = ctx.saved_tensors
+        ns, c = x.shape[-2], x.shape[-1]
+        groups = x.numel() // (ns * c)
+        grad_x = torch.empty_like(x)
+        gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_max_pool_bwd(x, grad_out.contiguous().float(), arg, weight, bias, stats, grad_x, gw, gb, scratch, groups, ns, c)
+        return grad_x, gw, gb, None, None, None, None
+
+
+def batch_norm_relu_max_pool(bn, x):
+    """max over dim -2 of relu(bn(x)) for an nn.BatchNorm{1,2}d module over the last dim of x (training mode)."""
+    bump_bn_counter(bn)
+    rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+    return BatchNormReLUMaxPool.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum)
+
+
 # num_batches_tracked bookkeeping: 51 one-element `add_` launches per step when every layer bumps its own
 # counter.  IASSD_Backbone.forward collects them here and bumps them with one _foreach_add_ at the end.
 BN_COUNTERS_PENDING = None

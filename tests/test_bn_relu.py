@@ -96,3 +96,33 @@ def test_dense_bf16_boundary_variants(rows, c):
         assert gx.dtype == x.dtype
         assert torch.equal(gg, gg0) and torch.equal(gb_, gb0)
         assert torch.equal(gx, gx0 if x.dtype == torch.float32 else gx0.bfloat16())
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 16, 64), (1, 300, 32, 512), (3, 7, 1, 8), (2, 64, 64, 256)])
+@pytest.mark.parametrize("bf16_x", [False, True])
+def test_bn_relu_max_pool_fused(shape, bf16_x):
+    """BatchNormReLUMaxPool == max over nsample of BatchNormReLU: same forward values and running statistics bit for bit,
+    gradients within fp32 re-association noise (the dense gradient of the max-pool is generated on the fly)."""
+    from pdanet_amd import pointnet2_utils as pu
+    torch.manual_seed(sum(shape))
+    c = shape[-1]
+    bns = [nn.BatchNorm2d(c).cuda().train() for _ in range(2)]
+    with torch.no_grad():
+        bns[0].weight.uniform_(0.5, 1.5); bns[0].bias.normal_(0, 0.3)
+        bns[1].load_state_dict(bns[0].state_dict())
+    x0 = torch.randn(shape, device="cuda") * 1.5 + 0.3
+    if bf16_x:
+        x0 = x0.bfloat16()
+    xs = [x0.clone().requires_grad_(True) for _ in range(2)]
+    assert pu.BatchNormReLUMaxPool.supported(xs[0], bns[0])
+    y_f = pu.batch_norm_relu_max_pool(bns[0], xs[0])
+    y_u = pu.batch_norm_relu(bns[1], xs[1]).max(dim=-2)[0]
+    assert y_f.dtype == torch.float32 and torch.equal(y_f, y_u)
+    assert torch.equal(bns[0].running_mean, bns[1].running_mean) and torch.equal(bns[0].running_var, bns[1].running_var)
+    go = torch.randn_like(y_f)
+    gf = torch.autograd.grad(y_f, [xs[0], bns[0].weight, bns[0].bias], go)
+    gu = torch.autograd.grad(y_u, [xs[1], bns[1].weight, bns[1].bias], go)
+    assert gf[0].dtype == x0.dtype
+    tol = 2e-2 if bf16_x else 2e-5
+    for a, b in zip(gf, gu):
+        assert (a.double() - b.double()).abs().max().item() <= tol * max(1e-3, b.double().abs().max().item())
