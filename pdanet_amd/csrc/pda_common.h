@@ -61,10 +61,16 @@ __device__ __forceinline__ float sqdist3(float ax, float ay, float az, float bx,
 // straight out of bf16 GEMMs and out / dqkv go straight into them.  All arithmetic is fp32 either way.
 typedef uint16_t bf16_t;
 __device__ __forceinline__ float bf16_to_f32(bf16_t u) { return __uint_as_float((uint32_t)u << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round to nearest even; NaN stays NaN
-    const uint32_t b = __float_as_uint(f);
-    return (f != f) ? (bf16_t)0x7fc0 : (bf16_t)((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+// f32 -> bf16 through the hardware conversion (v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN).  The usual
+// integer recipe (u + 0x7fff + ((u >> 16) & 1)) >> 16 turns some NaNs into 0 or infinity, and a guard "f != f" does not
+// survive -fno-honor-nans (MI355X_MICROARCH.md, correctness boundaries).
+typedef __bf16 pda_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float pda_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    const pda_f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, pda_bf16x2));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
 __device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 load4(const bf16_t* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
@@ -74,8 +80,8 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
 __device__ __forceinline__ void store4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
 __device__ __forceinline__ void store4(bf16_t* p, const float4& v) {
     uint2 u;
-    u.x = (uint32_t)f32_to_bf16(v.x) | ((uint32_t)f32_to_bf16(v.y) << 16);
-    u.y = (uint32_t)f32_to_bf16(v.z) | ((uint32_t)f32_to_bf16(v.w) << 16);
+    u.x = f32x2_to_bf16x2(v.x, v.y);
+    u.y = f32x2_to_bf16x2(v.z, v.w);
     *reinterpret_cast<uint2*>(p) = u;
 }
 __device__ __forceinline__ float load1(const float* p) { return *p; }

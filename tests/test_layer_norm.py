@@ -168,3 +168,19 @@ def test_add_max_pool_dense_bf16_variants(G, S, D):
     ext.max_pool_scatter(go, outs[0][1], gx, G, S, D)
     ext.max_pool_scatter(go, outs[0][1], gx2, G, S, D, grad_x_bf16=gxb)
     assert torch.equal(gx, gx2) and torch.equal(gxb, gx.bfloat16())
+
+
+def test_bf16_emission_keeps_nan_and_inf():
+    """The bf16 copies are rounded by the hardware conversion: NaN stays NaN, infinities stay infinities (an integer
+    rounding recipe turns some NaNs into 0 / inf)."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    G, S, D = 3, 4, 8
+    go = torch.randn(G, D, device="cuda")
+    go[0, 0] = float("nan"); go[1, 1] = float("inf"); go[2, 2] = float("-inf")
+    go[0, 3] = float("nan")
+    arg = torch.zeros(G, D, device="cuda", dtype=torch.uint8)
+    gx, gxb = torch.empty(G, S, D, device="cuda"), torch.empty(G, S, D, device="cuda", dtype=torch.bfloat16)
+    ext.max_pool_scatter(go, arg, gx, G, S, D, grad_x_bf16=gxb)
+    assert torch.equal(gxb.isnan(), gx.isnan()) and gxb.isnan().sum().item() == 2
+    assert torch.equal(gxb.isinf(), gx.isinf()) and gxb.isinf().sum().item() == 2
+    assert torch.equal(torch.nan_to_num(gxb.float()), torch.nan_to_num(gx.bfloat16().float()))
