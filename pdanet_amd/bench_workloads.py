@@ -110,6 +110,23 @@ class BackboneWorkload:
                 pass
         return None
 
+    @staticmethod
+    def _pmc_mfma_util(prefix):
+        """MFMA-pipe busy fraction of a kernel from the committed counter pass (profiles/r*_pmc/mfma_util.json): the
+        launch shape with the most launches; None when no pass is committed."""
+        import glob
+        import json
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        best = None
+        for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc", "mfma_util.json"))):
+            try:
+                for name, k in json.load(open(f))["kernels"].items():
+                    if name.startswith(prefix) and (best is None or k["launches"] > best["launches"]):
+                        best = k
+            except (OSError, ValueError, KeyError):
+                pass
+        return None if best is None else round(best["mfma_util"], 4)
+
     def roofline_mfma(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
         2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration."""
@@ -124,7 +141,8 @@ class BackboneWorkload:
         peak = 157.3
         total = sum(sum(v) for v in by.values())
         steps = max(1, len(self.fps_events))          # one D-FPS launch per step
-        return {"kernel": "wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t), "bound": "mfma",
+        pmc = self._pmc_mfma_util("pda::wgrad_kernel")
+        return {"kernel": "wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t), "bound": "mfma", "mfma_busy_pmc": pmc,
                 "achieved": flops / avg / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / avg / 1e12 / peak,
                 "traffic": self._pmc_traffic("pda::wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t)), "avg_launch_ms": avg * 1e3,
                 "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); traffic = committed PMC passes (profiles/r01_pmc);  event-timed launch = split-K kernel + fixed-order "
