@@ -126,3 +126,40 @@ def test_bn_relu_max_pool_fused(shape, bf16_x):
     tol = 2e-2 if bf16_x else 2e-5
     for a, b in zip(gf, gu):
         assert (a.double() - b.double()).abs().max().item() <= tol * max(1e-3, b.double().abs().max().item())
+
+
+def test_eval_bn_folding_matches_unfolded_mlp():
+    """Inference: [Conv1x1 -> BN(eval) -> ReLU]* with the BatchNorm folded into the convolution weights (and the ReLU in
+    the GEMM epilogue) against the op-by-op path; with and without the max-pool tail."""
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(5)
+    layers = []
+    c_in = 19
+    for c_out in (32, 64, 128):
+        layers += [nn.Conv2d(c_in, c_out, 1, bias=(c_out == 64)), nn.BatchNorm2d(c_out), nn.ReLU()]
+        c_in = c_out
+    mlp = nn.Sequential(*layers).cuda().eval()
+    with torch.no_grad():
+        for m in mlp:
+            if isinstance(m, nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.5); m.running_var.uniform_(0.5, 2.0); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+    x = torch.randn(2, 50, 16, 19, device="cuda")
+    outs = {}
+    with torch.no_grad():
+        for fold in (True, False):
+            pm.FOLD_EVAL_BN = fold
+            try:
+                outs[fold] = (pm._mlp_lastdim(mlp, x), pm._mlp_lastdim(mlp, x, pool=True))
+            finally:
+                pm.FOLD_EVAL_BN = True
+        ref = mlp(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape and torch.allclose(a, b, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(outs[True][0], ref, atol=2e-5, rtol=1e-5)
+    assert torch.allclose(outs[True][1], ref.max(dim=2)[0], atol=2e-5, rtol=1e-5)
+    # a parameter update invalidates the cached folded weights
+    with torch.no_grad():
+        mlp[0].weight.mul_(2.0)
+        again = pm._mlp_lastdim(mlp, x)
+        ref2 = mlp(x.permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    assert torch.allclose(again, ref2, atol=4e-5, rtol=1e-5)
