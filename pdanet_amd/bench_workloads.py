@@ -285,7 +285,7 @@ class TrainStepWorkload(BackboneWorkload):
     def step(self):
         model = self.ddp if self.ddp is not None else self.model
         self.sched.step(self.it)
-        self.opt.zero_grad()
+        self.opt.zero_grad(set_to_none=self.ddp is None)    # DDP copies its reduced buckets into the flat-buffer views
         bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
         loss = self.loss_of(bd)
         loss.backward()
@@ -319,7 +319,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
     def step(self):
         model = self.ddp if self.ddp is not None else self.model
         self.sched.step(self.it)
-        self.opt.zero_grad()
+        self.opt.zero_grad(set_to_none=self.ddp is None)    # DDP copies its reduced buckets into the flat-buffer views
         ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt, 'inputs_resident': True})
         ret['loss'].backward()
         self.opt.step()

@@ -234,7 +234,7 @@ class IASSD_Head(nn.Module):  # noqa: N801
         mean = torch.zeros(B * S + 1, 3, device=pred.device, dtype=pred.dtype).index_add_(0, seg, pred * ones[:, None])
         mean = mean / cnt.clamp(min=1.0)[:, None]
         l_gt = F.smooth_l1_loss(pred, gt[:, 0:3], reduction='none').sum(-1)
-        l_mean = F.smooth_l1_loss(pred, mean[seg], reduction='none').sum(-1)
+        l_mean = F.smooth_l1_loss(pred, mean.index_select(0, seg), reduction='none').sum(-1)   # backward: one index_add (mean[seg]: a sort-based scatter, 0.6 ms)
         per_pt = torch.where(valid, l_gt + 0.5 * l_mean, torch.zeros_like(l_gt))
         per_ins = torch.zeros(B * S + 1, device=pred.device, dtype=pred.dtype).index_add_(0, seg, per_pt) / cnt.clamp(min=1.0)
         present = (cnt[:-1] > 0).to(pred.dtype)

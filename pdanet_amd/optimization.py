@@ -127,17 +127,48 @@ class FlatAdamOneCycle:
                 self.flat_p[o:o + n].copy_(p.data.reshape(-1))
                 p.data = self.flat_p[o:o + n].view(p.shape)
             p.grad = self.flat_g[o:o + n].view(p.shape)
+        self._all = everything
+        self._grad_views = [p.grad for p in everything]
+        self._gather = False
         self.params = trained
         self.wd, self.beta2, self.eps, self.grad_norm_clip = wd, beta2, eps, grad_norm_clip
         self.lr, self.mom = lr, mom
         self.step_count = 0
 
-    def zero_grad(self):
-        self.flat_g.zero_()     # gradients stay views of flat_g (never set to None)
+    def zero_grad(self, set_to_none=False):
+        """Default: zero the flat gradient buffer; `.grad` stay views of it, so autograd ACCUMULATES into them (one small
+        add launch per parameter per backward -- ~300 launches for PDA-SSD).  set_to_none=True: `.grad` = None, autograd
+        hands each parameter its gradient tensor as produced, and step() gathers them into the flat buffer with one
+        multi-tensor copy (a handful of launches).  Same result; use the default when something else (DDP built with
+        `grads_are_views`) writes into the views."""
+        if set_to_none:
+            for p in self._all:
+                p.grad = None
+            self._gather = True
+        else:
+            if self._gather:
+                for p, v in zip(self._all, self._grad_views):
+                    p.grad = v
+                self._gather = False
+            self.flat_g.zero_()
+
+    def _gather_grads(self):
+        self.flat_g.zero_()                                  # slots of parameters that received no gradient
+        dsts, srcs = [], []
+        for p, v in zip(self._all, self._grad_views):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dsts.append(v); srcs.append(g.detach())
+            p.grad = v                                       # .grad is a view of flat_g again (total_norm, checkpoints, hooks)
+        if srcs:
+            torch._foreach_copy_(dsts, srcs)
+        self._gather = False
 
     def step(self):
         """clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP) + OptimWrapper.step()."""
         lib = _lib.load()
+        if self._gather:
+            self._gather_grads()
         stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream
         with torch.cuda.device(self.flat_p.device):
             norm_ptr = None

@@ -148,3 +148,32 @@ def test_derived_tensor_caches_follow_the_raw_pointer_optimizer():
         s = bn.weight * torch.rsqrt(bn.running_var + bn.eps)
         assert not torch.equal(w1, w0)
         assert torch.allclose(w1, conv.weight.flatten(1) * s[:, None])
+
+
+@pytest.mark.gpu
+def test_set_to_none_gather_path_equals_accumulating_views():
+    """zero_grad(set_to_none=True): autograd hands out fresh gradient tensors and step() gathers them with one
+    multi-tensor copy.  Same parameters, norm and moments as the default path (gradients accumulated into the views),
+    including a parameter that receives no gradient and two backward passes accumulated into one step."""
+    from pdanet_amd import optimization
+    results = []
+    for mode in (False, True):
+        torch.manual_seed(11)
+        model = nn.Sequential(nn.Linear(6, 16), nn.ReLU(), nn.Linear(16, 4), nn.Linear(4, 3)).cuda()
+        opt = optimization.FlatAdamOneCycle(model, wd=0.01, lr=5e-3, grad_norm_clip=0.5)
+        x = torch.randn(32, 6, device="cuda")
+        norms = []
+        for it in range(4):
+            opt.zero_grad(set_to_none=mode)
+            h = model[2](model[1](model[0](x)))              # model[3] unused: no gradient this step
+            h.square().mean().backward()
+            if it == 2:
+                (h.detach() * 0 + model[2](model[1](model[0](x * 0.5)))).abs().mean().backward()   # accumulate a second backward
+            opt.step()
+            norms.append(float(opt.total_norm))
+            for p in model.parameters():                     # .grad are views of the flat buffer after step()
+                assert p.grad is not None and opt.flat_g.data_ptr() <= p.grad.data_ptr() < opt.flat_g.data_ptr() + 4 * opt.flat_g.numel()
+        results.append((norms, opt.flat_p.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone()))
+    (na, pa, ma, va), (nb, pb, mb, vb) = results
+    assert na == pytest.approx(nb, rel=1e-6)
+    assert torch.allclose(pa, pb, atol=1e-7, rtol=1e-6) and torch.allclose(ma, mb, atol=1e-9, rtol=1e-5) and torch.allclose(va, vb, atol=1e-12, rtol=1e-5)
