@@ -162,6 +162,22 @@ int pda_pda_geometry(const float *xyz, const float *new_xyz, const int32_t *idx,
  * entries of points in no box are NOT written (the caller pre-fills -1, roiaware_pool3d_utils.py:41). */
 int pda_points_in_boxes(const float *boxes, const float *pts, int32_t *box_idx_of_points, int b, int t,
                         int m, pda_stream_t stream);
+/* The point-wise remainder of the IA-SSD head's target assignment (IASSD_head.py:132-277 after the two points_in_boxes
+ * queries), one launch per point set: from in_box / in_ext (B, N) = index of the ground-truth box / enlarged box each point
+ * lies in (-1: none) and gt_boxes (B, T, 8) [x y z dx dy dz heading class]:
+ *   mode 0 (set_ignore_flag, :207-217)   foreground = in a box; points only inside the enlarged box get label -1
+ *   mode 1 (use_ex_gt_assign, :190-205)  foreground = in an enlarged box; instance points keep their own box index
+ *   mode 2 (mode 1 + fg_pc_ignore)       foreground = in the enlarged box only; box index -1 for the instance points
+ * labels (B*N) int64: 0 background, -1 ignored, else the class of the box (1 when single_class); box_idx (B*N) int64;
+ * gt_of_points (B*N, 8) = gt_boxes[scene][box index], index -1 wrapping to the last row as the reference's indexing does. */
+int pda_assign_point_targets(const float *gt_boxes, const int32_t *in_box, const int32_t *in_ext, int64_t *labels,
+                             int64_t *box_idx, float *gt_of_points, int b, int n, int t, int mode, int single_class,
+                             pda_stream_t stream);
+/* Soft instance labels of gauss_fun_once_topk_GT_add_same_size (IASSD_head.py:889-963): out[p] = exp(-0.5 |S d|^2) where
+ * labels[p] > 0, else 0; d = offset of point p (coords + p*stride + offset: x, y, z) in the frame of its box
+ * gt_of_points[p], S = diag(4/(w^2+l^2), 4/(w^2+h^2), 4/(h^2+l^2)) times 4 / 6 / 5 for classes 1 / 2 / 3. */
+int pda_sa_gaussian_mask(const float *coords, int stride, int offset, const float *gt_of_points, const int64_t *labels,
+                         float *out, int64_t points, pda_stream_t stream);
 
 /* ---- rotated BEV overlap / IoU / NMS (pcdet/ops/iou3d_nms) --------------------------------------
  * replace boxes_overlap_bev_gpu / boxes_iou_bev_gpu (src/iou3d_nms.cpp:40-63 / :65-87 ->

@@ -33,6 +33,8 @@ def _get(cfg, key, default=None):
     return cfg.get(key, default) if hasattr(cfg, "get") else getattr(cfg, key, default)
 
 
+FUSED_HEAD_TARGETS = True   # csrc/head_targets.hip instead of ~20-30 elementwise launches per point set
+
 class IASSD_Head(nn.Module):  # noqa: N801
     def __init__(self, num_class, input_channels, model_cfg, predict_boxes_when_training=False, **kwargs):
         super().__init__()
@@ -92,6 +94,20 @@ class IASSD_Head(nn.Module):  # noqa: N801
         assert points.shape[0] % B == 0, "scenes must contribute equally many points"
         xyz = points[:, 1:4].reshape(B, -1, 3).contiguous()
         N = xyz.shape[1]
+        if FUSED_HEAD_TARGETS and xyz.is_cuda and (use_ex_gt_assign or set_ignore_flag):
+            # two box queries + ONE launch for everything point-wise that follows (csrc/head_targets.hip)
+            in_box = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, gt_boxes[:, :, 0:7].contiguous())
+            in_ext = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, extend_gt_boxes[:, :, 0:7].contiguous())
+            mode = (2 if fg_pc_ignore else 1) if use_ex_gt_assign else 0
+            labels, idx, gt_of_pts = roiaware_pool3d_utils.assign_point_targets(
+                gt_boxes.contiguous(), in_box, in_ext, mode, self.num_class == 1 or binary_label)
+            box_labels = None
+            if ret_box_labels:                                                        # :246-259
+                enc = self.box_coder.encode_torch(gt_of_pts[:, :-1], xyz.reshape(B * N, 3),
+                                                  gt_classes=gt_of_pts[:, -1].long().clamp(min=1))
+                box_labels = torch.where((labels > 0).reshape(-1, 1), enc, torch.zeros_like(enc))
+            return {'point_cls_labels': labels, 'point_box_labels': box_labels, 'box_idxs_labels': idx,
+                    'gt_box_of_points': gt_of_pts}
         in_box = roiaware_pool3d_utils.points_in_boxes_gpu(xyz, gt_boxes[:, :, 0:7].contiguous()).long()
         box_fg = in_box >= 0
         labels = torch.zeros_like(in_box)
@@ -307,6 +323,10 @@ class IASSD_Head(nn.Module):  # noqa: N801
         r = self.forward_ret_dict
         masks = []
         for labels, gt, coords in zip(r['sa_ins_labels'], r['sa_gt_box_of_points'], r['sa_xyz_coords']):
+            if FUSED_HEAD_TARGETS and gt.is_cuda and gt.shape[-1] == 8:
+                c2 = coords.detach().reshape(-1, coords.shape[-1]).contiguous()
+                masks.append(roiaware_pool3d_utils.sa_gaussian_mask(c2, gt.contiguous(), labels.reshape(-1).contiguous()))
+                continue
             pos = labels > 0
             xyz = coords.reshape(-1, coords.shape[-1])[:, 1:4].detach()
             off = box_utils.rotate_points_along_z((xyz - gt[:, 0:3]).unsqueeze(1), -gt[:, 6]).squeeze(1)

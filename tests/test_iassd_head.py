@@ -119,3 +119,46 @@ def test_loss_path_has_no_host_sync():
     finally:
         torch.cuda.set_sync_debug_mode("default")
     assert torch.isfinite(loss)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kwargs", [dict(set_ignore_flag=True), dict(set_ignore_flag=True, ret_box_labels=True),
+                                    dict(use_ex_gt_assign=True, set_ignore_flag=False),
+                                    dict(use_ex_gt_assign=True, fg_pc_ignore=True, ret_box_labels=True),
+                                    dict(set_ignore_flag=True, binary_label=True)])
+def test_fused_target_kernels_equal_the_torch_formulation(kwargs):
+    """csrc/head_targets.hip (one launch per point set) against the elementwise torch formulation of the same assignment:
+    labels, box indices, gathered boxes and box-coder targets identical; the soft instance masks within 1e-6."""
+    from pdanet_amd import iassd_head
+    _, head, bd, _ = _prepare("once", "cuda")
+    B = bd["batch_size"]
+    gt = bd["gt_boxes"]
+    gt8 = torch.cat((gt[..., 0:7], gt[..., -1:]), dim=-1) if gt.shape[-1] == 10 else gt
+    from pdanet_amd import box_utils
+    ext = box_utils.enlarge_box3d(gt8.view(-1, 8), extra_width=[0.5, 0.5, 0.5]).view(B, -1, 8)
+    pts = bd["encoder_coords"][1].reshape(-1, 4)
+    outs = []
+    for fused in (True, False):
+        iassd_head.FUSED_HEAD_TARGETS = fused
+        try:
+            outs.append(head.assign_stack_targets_IASSD(pts, gt8, ext, **kwargs))
+        finally:
+            iassd_head.FUSED_HEAD_TARGETS = True
+    a, b = outs
+    assert (a["point_cls_labels"] != 0).any()
+    for k in ("point_cls_labels", "box_idxs_labels", "gt_box_of_points"):
+        assert torch.equal(a[k], b[k]), k
+    if kwargs.get("ret_box_labels"):
+        assert torch.equal(a["point_box_labels"], b["point_box_labels"])
+    # soft masks
+    head.forward_ret_dict = {"sa_ins_labels": [a["point_cls_labels"]], "sa_gt_box_of_points": [a["gt_box_of_points"]],
+                             "sa_xyz_coords": [bd["encoder_coords"][1]]}
+    masks = []
+    for fused in (True, False):
+        iassd_head.FUSED_HEAD_TARGETS = fused
+        try:
+            masks.append(head.sa_gaussian_masks()[0])
+        finally:
+            iassd_head.FUSED_HEAD_TARGETS = True
+    assert masks[0].shape == masks[1].shape and (masks[0] > 0).any()
+    assert torch.allclose(masks[0], masks[1], atol=1e-6, rtol=1e-5)
