@@ -111,9 +111,9 @@ class BackboneWorkload:
         return None
 
     @staticmethod
-    def _pmc_mfma_util(prefix):
+    def _pmc_mfma_util(prefix, by="launches"):
         """MFMA-pipe busy fraction of a kernel from the committed counter pass (profiles/r*_pmc/mfma_util.json): the
-        launch shape with the most launches; None when no pass is committed."""
+        launch shape with the most launches (or the longest one, by="avg_ns"); None when no pass is committed."""
         import glob
         import json
         root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -121,7 +121,7 @@ class BackboneWorkload:
         for f in sorted(glob.glob(os.path.join(root, "profiles", "r*_pmc", "mfma_util.json"))):
             try:
                 for name, k in json.load(open(f))["kernels"].items():
-                    if name.startswith(prefix) and (best is None or k["launches"] > best["launches"]):
+                    if name.startswith(prefix) and (best is None or k[by] > best[by]):
                         best = k
             except (OSError, ValueError, KeyError):
                 pass
@@ -251,6 +251,7 @@ class BackboneInferWorkload(BackboneWorkload):
         return {"kernel": "sa_mlp_kernel %s ns=%d (%d scenes/launch)" % ("->".join(map(str, dims)), ns, self.B),
                 "bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": None, "avg_launch_ms": t * 1e3,
+                "mfma_busy_pmc": self._pmc_mfma_util("pda::sa_mlp_kernel", by="avg_ns"),
                 "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32); layer 5, all scales: %.1f GFLOP in %.3f ms = "
                         "%.1f TFLOP/s = %.1f %% of peak" % (l5_f / 1e9, l5_t * 1e3, l5_f / l5_t / 1e12,
                                                             100 * l5_f / l5_t / 1e12 / peak) if l5_t > 0 else ""}
