@@ -1,230 +1,158 @@
 #!/usr/bin/env python
 """bench.py -- scenes/sec of the PDA-SSD hot path on MI355X (BASELINE.json metric).
 
-  python bench.py --gpus N --steps K --warmup W
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py --gpus N --steps K --warmup W           (N > 1: spawns its own N ranks, see below)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+         bench.py --gpus N --steps K --warmup W           (the driver's form: RANK/LOCAL_RANK/WORLD_SIZE from env)
 
-A step = one pass of the hot path over one per-GPU batch of synthetic scenes (ONCE,
-16384 points, batch 2 per GPU = BASELINE configs[1]; weak scaling: every rank processes its
-own scenes, no data-path collective for the forward workload).  Inputs are resident in HBM
-before the timed region.  One JSON line is printed by rank 0.
+A step = one pass of the hot path over one per-GPU batch of synthetic scenes (ONCE, 16384 points, batch 2 per
+GPU as in the ONCE yaml; weak scaling: every rank processes its own scenes, the only exchange step is DDP's
+gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-Workloads (--workload):
-  sampling_grouping  the sampling/grouping operators of the PDA-SSD backbone at the ONCE
-                     16384-pt layer shapes: FPS, ball queries, gathers,
-                     groupings -- the operators this repo implements as HIP kernels.
-  backbone           full backbone forward+backward (default; BASELINE's metric).
+Launch contract (reference: tools/scripts/torch_train.sh:17, dist_train.sh:18 start one process per GPU):
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this file under torch.distributed.run with
+N ranks BEFORE anything touches the GPU (a child process, never an exec) and exits with its code; under a
+launcher, WORLD_SIZE must equal --gpus or the run stops with exit code 2 -- a single-rank run is never reported
+as an N-GPU result.
+
+Workloads (--workload; default detector_train):
+  detector_train     backbone + IA-SSD head (target assignment, all losses) + backward + grad clip + adam_onecycle:
+                     the reference's whole training iteration (train_utils.py:34-64) on synthetic scenes and boxes.
+  backbone           backbone forward+backward with a synthetic loss (round 1's headline; now under `extra`).
   backbone_infer     backbone forward, eval BN, fused SA kernel (BASELINE configs[1]).
-  train_step         backbone forward+backward + grad clip + adam_onecycle step (csrc/optim.hip).
-  backbone_bf16      backbone forward+backward in dense-bf16 mode (DESIGN.md "Dense-bf16 mode": bf16 GEMMs with fp32
-                     accumulation, GEMM-adjacent tensors stored as bf16; residual stream, statistics and the
-                     kernels' arithmetic fp32).
-  backbone_infer_bf16   backbone_infer in dense-bf16 mode.
-  kitti_train_bf16   train_step on the KITTI yaml in dense-bf16 mode (use --batch 4).
-  detector_train     backbone + IA-SSD head (target assignment, all losses) + grad clip + adam_onecycle:
-                     the reference's whole training iteration on synthetic scenes and boxes.
-  kitti_detector_train_bf16   the same on the KITTI yaml in dense-bf16 mode (BASELINE configs[2]; --batch 4).
+  kitti_detector_train_bf16   detector_train on the KITTI yaml in dense-bf16 mode (BASELINE configs[2]; --batch 4).
+  train_step, kitti_train_bf16, backbone_bf16, backbone_infer_bf16   see benchmarks/workloads.py.
+  sampling_grouping  only the sampling/grouping operators at the ONCE-16k layer shapes.
+
+The default run (N = 1) also times `backbone`, `backbone_infer` and `kitti_detector_train_bf16 --batch 4` for a
+few steps each and reports them under "extra" (--no-extra skips that).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
-import torch.distributed as dist
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 
-# ONCE PDA-SSD layer shapes at N_in = 16384:
-#   (centres M, points N, [(radius, nsample)], feature channels C)
-ONCE16K_LAYERS = [
-    dict(name="L0", M=16384, N=16384, scales=[(0.2, 16), (0.8, 32)], C=1, fps=None),
-    dict(name="L1", M=4096, N=16384, scales=[(0.8, 16), (1.6, 32)], C=64, fps=(16384, 4096)),
-    dict(name="L2", M=2048, N=4096, scales=[(1.6, 16), (4.8, 32)], C=128, fps=None),
-    dict(name="L5", M=1024, N=2048, scales=[(4.8, 16), (8.4, 32), (12.8, 64)], C=256, fps=None),
-]
-
-
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/r*_pmc/traffic.json);
-    PMC counters cannot be read from inside the process, so bench.py reports the recorded value."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", "traffic.json"))):
-        try:
-            for k, d in json.load(open(f))["kernels"].items():
-                if k.startswith(kernel_prefix):
-                    best = d["hbm_bytes_per_launch_mean"]
-        except (OSError, ValueError, KeyError):
-            pass
-    return best
-
-
-def fps_algorithmic_bytes(n, m):
-    return (m - 1) * n * 20 + m * 4  # BASELINE.md section 2, per scene
-
-
-class SamplingGroupingWorkload:
-    """All sampling/grouping operator calls of one PDA-SSD backbone forward (ONCE-16k)."""
-
-    name = "once16k_b2_sampling_grouping"
-
-    def __init__(self, batch, n_points, device, rank):
-        from pdanet_amd import pointnet2_utils as pu, synth
-        self.pu = pu
-        self.B, self.N = batch, n_points
-        xyz = synth.batch_xyz(batch, n_points, config_id=2 + 10 * rank, dist="L")
-        self.xyz_np = xyz
-        self.xyz = torch.from_numpy(xyz).to(device)
-        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
-        self.feats = {L["name"]: torch.randn(batch, L["C"], L["N"], generator=g).to(device)
-                      for L in ONCE16K_LAYERS}
-        self.fps_events = []
-        self.record = False
-
-    def step(self):
-        pu = self.pu
-        xyz = self.xyz
-        out = 0
-        for L in ONCE16K_LAYERS:
-            pts = xyz[:, :L["N"]].contiguous() if L["N"] != xyz.shape[1] else xyz
-            if L["fps"] is not None:
-                if self.record:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                idx = pu.furthest_point_sample(pts, L["M"])
-                if self.record:
-                    e1.record()
-                    self.fps_events.append((e0, e1, pts.shape[1], L["M"]))
-                new_xyz = pu.gather_operation(pts.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
-            else:
-                new_xyz = pts[:, :L["M"]].contiguous()
-            idxs = pu.ball_query_multi([r for r, _ in L["scales"]], [ns for _, ns in L["scales"]], pts, new_xyz)
-            pts_t = pts.transpose(1, 2).contiguous()
-            for idx_s in idxs:
-                gx = pu.grouping_operation(pts_t, idx_s)
-                gf = pu.grouping_operation(self.feats[L["name"]], idx_s)
-                out = out + gx.numel() + gf.numel()
-            xyz = new_xyz if L["name"] != "L5" else xyz
-        return out
-
-    def fps_shape(self):
-        return 16384, 4096
-
-    def cpu_baseline(self, budget_s=20.0):
-        """The same operator sequence through the CPU oracle (kind 'port'), on scene 0."""
-        import oracle
-        nthreads = oracle.num_threads()
-        xyz = np.ascontiguousarray(self.xyz_np[:1])
-        t0 = time.perf_counter()
-        cur = xyz
-        for L in ONCE16K_LAYERS:
-            pts = np.ascontiguousarray(cur[:, :L["N"]])
-            n = pts.shape[1]
-            if L["fps"] is not None:
-                temp = np.full((1, n), 1e10, np.float32)
-                idx = np.zeros((1, L["M"]), np.int32)
-                oracle.farthest_point_sampling_wrapper(1, n, L["M"], pts, temp, idx)
-                new_xyz = np.ascontiguousarray(pts[0][idx[0]][None])
-            else:
-                new_xyz = np.ascontiguousarray(pts[:, :L["M"]])
-            feats = np.zeros((1, L["C"], n), np.float32)
-            pts_t = np.ascontiguousarray(pts.transpose(0, 2, 1))
-            for r, ns in L["scales"]:
-                bq = np.zeros((1, L["M"], ns), np.int32)
-                oracle.ball_query_wrapper(1, n, L["M"], r, ns, new_xyz, pts, bq)
-                gx = np.empty((1, 3, L["M"], ns), np.float32)
-                oracle.group_points_wrapper(1, 3, n, L["M"], ns, pts_t, bq, gx)
-                gf = np.empty((1, L["C"], L["M"], ns), np.float32)
-                oracle.group_points_wrapper(1, L["C"], n, L["M"], ns, feats, bq, gf)
-            cur = new_xyz if L["name"] != "L5" else cur
-        dt = time.perf_counter() - t0
-        return dict(value=1.0 / dt, unit="scenes/s", cores=nthreads, kind="port",
-                    sample="1 scene (scene 0 of the GPU batch), same operator sequence through "
-                           "oracle/libpda_oracle.so (OpenMP, %d threads), %.2f s" % (nthreads, dt))
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="auto")
-    ap.add_argument("--batch", type=int, default=2, help="scenes per GPU (ONCE yaml: 2)")
+    ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the yaml's 2 for ONCE, 4 for KITTI)")
     ap.add_argument("--points", type=int, default=16384)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary timings under 'extra'")
+    return ap.parse_args(argv)
 
+
+def spawn_ranks(args, argv):
+    """--gpus N without a launcher: start N ranks of this file under torch.distributed.run as a CHILD process.
+    Nothing in this process has touched the GPU yet (torch is not even imported)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.call(cmd, env=env)
+
+
+def time_workload(wl, steps, warmup, device, parallel):
+    """W (+2 priming) untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over
+    ranks.  The two priming steps keep first-use costs (code-object loading of every library GEMM, allocator
+    growth, TunableOp table lookups) out of a run with a small W."""
+    wl.begin()
+    for _ in range(2 + warmup):
+        wl.step()
+    parallel.barrier(device)
+    wl.record = True
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        wl.step()
+    parallel.barrier(device)
+    dt = time.perf_counter() - t0
+    wl.record = False
+    return parallel.max_over_ranks(dt, device)
+
+
+def metric_name(wl_name, points):
+    ds = "KITTI" if wl_name.startswith("kitti") else "ONCE"
+    if "fwd_bwd" in wl_name:
+        what = "forward+backward"
+    elif "fwd_eval" in wl_name:
+        what = "forward"
+    else:
+        what = "sampling/grouping ops"
+    return "scenes/sec (%d-pt %s, PDA-SSD %s)" % (points, ds, what)
+
+
+STEP_TEXT = {
+    "detector": "IASSD detector (backbone + IA-SSD head with target assignment and all losses) forward, backward, "
+                "gradient clipping, adam_onecycle step = the reference's training iteration (train_utils.py:34-64)",
+    "backbone_fwd_bwd_adam": "backbone forward + synthetic loss + backward + gradient clipping + adam_onecycle step",
+    "backbone_fwd_bwd": "backbone forward + synthetic L2 loss on every head input + backward",
+    "backbone_fwd_eval": "backbone forward, eval BatchNorm, fused SA kernel, no_grad",
+    "sampling_grouping": "sampling/grouping operators only",
+}
+
+
+def step_text(name):
+    for k, v in STEP_TEXT.items():
+        if k in name:
+            return v
+    return name
+
+
+def main():
+    argv = sys.argv[1:]
+    args = parse_args(argv)
+    env_world = int(os.environ["WORLD_SIZE"]) if "WORLD_SIZE" in os.environ else None
+    if args.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(args, argv))
+    if env_world is not None and env_world != args.gpus:
+        print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks; refusing to report a mislabelled "
+              "run" % (args.gpus, env_world), file=sys.stderr)
+        sys.exit(2)
+
+    import torch
+    import torch.distributed as dist
+    from benchmarks import workloads
     from pdanet_amd import parallel
+
     rank, local_rank, world = parallel.env_world()
     assert torch.cuda.is_available(), "bench.py needs an MI355X (no CPU path)"
-    if os.environ.get("PDA_REHEARSE_ONE_GPU") == "1":     # several ranks on one card (with PDA_DIST_BACKEND=gloo)
+    rehearse = os.environ.get("PDA_REHEARSE_ONE_GPU") == "1"   # several ranks on one card (with PDA_DIST_BACKEND=gloo)
+    if rehearse:
         local_rank = 0
+    elif torch.cuda.device_count() < world:
+        print("bench.py: %d ranks but only %d GPUs visible" % (world, torch.cuda.device_count()), file=sys.stderr)
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     parallel.init_distributed("nccl", device)  # backend "nccl" is RCCL on ROCm; no-op for 1 GPU
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    seen_world = dist.get_world_size() if dist.is_initialized() else 1
+    assert seen_world == args.gpus, (seen_world, args.gpus)
+    backend = dist.get_backend() if dist.is_initialized() else None
 
-    workload = args.workload
-    if workload == "auto":
-        try:
-            from pdanet_amd import bench_workloads  # full backbone, when built
-            workload = bench_workloads.DEFAULT
-        except ImportError:
-            workload = "sampling_grouping"
-    if workload == "sampling_grouping":
-        wl = SamplingGroupingWorkload(args.batch, args.points, device, rank)
-    else:
-        from pdanet_amd import bench_workloads
-        wl = bench_workloads.create(workload, args.batch, args.points, device, rank, world)
+    name = workloads.DEFAULT if args.workload == "auto" else args.workload
+    batch = args.batch if args.batch is not None else (4 if name.startswith("kitti") else 2)
+    wl = workloads.create(name, batch, args.points, device, rank, world)
+    dt = time_workload(wl, args.steps, args.warmup, device, parallel)
+    roofs = wl.rooflines()
 
-    def barrier():
-        parallel.barrier(device)
-
-    # two untimed priming steps on top of the W warm-up steps: first-use costs (code-object loading of every
-    # library GEMM, MIOpen find, allocator growth, TunableOp table lookups) must not leak into a run with small W
-    for _ in range(2 + args.warmup):
-        wl.step()
-    barrier()
-    wl.record = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        wl.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    wl.record = False
-    dt = parallel.max_over_ranks(dt, device)
-
-    roof = wl.roofline() if hasattr(wl, "roofline") else None
-    if roof is None:
-        # dominant sampling kernel: FPS, timed live with events on the launch stream
-        n, m = wl.fps_shape()
-        fps_ms = [ev[0].elapsed_time(ev[1]) for ev in wl.fps_events if (ev[2], ev[3]) == (n, m)]
-        fps_avg_s = (sum(fps_ms) / max(1, len(fps_ms))) * 1e-3
-        alg_bytes = fps_algorithmic_bytes(n, m) * args.batch
-        achieved = alg_bytes / fps_avg_s / 1e9 if fps_avg_s > 0 else 0.0
-        roof = {
-            "kernel": "fps_pruned_kernel (FPS %d->%d, %d scenes/launch)" % (n, m, args.batch),
-            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic("pda::fps_pruned_kernel") if (n, m, args.batch) == (16384, 4096, 2) else None,
-            "avg_launch_ms": fps_avg_s * 1e3,
-            "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene) / kernel time; the kernel keeps "
-                    "the scene in registers (exact spatial pruning skips no-op updates), so real HBM traffic is the compulsory N*16+m*4 bytes; traffic = "
-                    "(2*FETCH_SIZE+WRITE_SIZE) KB per launch from profiles/r01_pmc (separate rocprofv3 --pmc passes)",
-        }
-
-    scenes = args.batch * world * args.steps
     line = {
-        "metric": "scenes/sec (%d-pt %s, PDA-SSD %s)" % (
-            args.points, "KITTI" if wl.name.startswith("kitti") else "ONCE", ("forward+backward+Adam" if "adam" in wl.name else "forward+backward") if "fwd_bwd" in wl.name else ("forward" if "fwd_eval" in wl.name else "sampling/grouping ops")),
-        "value": scenes / dt,
+        "metric": metric_name(wl.name, args.points),
+        "value": batch * world * args.steps / dt,
         "unit": "scenes/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -235,21 +163,48 @@ def main():
         "vs_baseline": None,
         "dtype": getattr(wl, "dtype", "f32"),
         "data": "synthetic",
-        "config": {"workload": wl.name, "scenes_per_gpu": args.batch, "points_per_scene": args.points,
-                   "parallelism": "dp%d" % world},
-        "roofline": roof,
+        "config": {"workload": wl.name, "step": step_text(wl.name), "scenes_per_gpu": batch,
+                   "global_batch": batch * world, "points_per_scene": args.points, "parallelism": "dp%d" % world,
+                   "world_size_seen": seen_world, "dist_backend": backend,
+                   "gradient_exchange": "DDP all-reduce over %s" % backend if getattr(wl, "ddp", None) is not None else None},
     }
-    if hasattr(wl, "roofline_mfma") and not hasattr(wl, "roofline"):
-        extra = wl.roofline_mfma()
-        if extra is not None:
-            line["roofline_mfma"] = extra      # second own kernel of the step, MFMA-bound (FPS above is latency/HBM)
+    line.update({k: v for k, v in roofs.items() if v is not None})
+    line.setdefault("roofline", None)
     if hasattr(wl, "tuned"):
         line["config"]["hipblaslt_tunableop_results_loaded"] = bool(wl.tuned)
+    line["config"]["peak_mem_GiB"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+
+    single = world == 1 and rank == 0
+    if single and not args.no_cpu_baseline:
+        line["cpu_baseline"] = wl.cpu_baseline()
+        # the operator baseline "at 1 thread and at all cores"
+        xyz_np = getattr(wl, "xyz_np", None)
+        if xyz_np is None:
+            xyz_np = wl.points_np[: args.points, 1:4].reshape(1, args.points, 3).copy()
+        line["cpu_baseline_ops"] = {"threads_1": workloads.sampling_grouping_cpu(xyz_np, 1),
+                                    "threads_all": workloads.sampling_grouping_cpu(xyz_np, None)}
+
+    if single and not args.no_extra and args.workload == "auto":
+        # secondary timings (few steps each): round 1's headline and BASELINE configs[1] / configs[2]
+        del wl
+        extra = {}
+        for xname, xbatch in (("backbone", 2), ("backbone_infer", 2), ("kitti_detector_train_bf16", 4)):
+            torch.cuda.empty_cache()
+            xw = workloads.create(xname, xbatch, args.points, device, rank, world)
+            xsteps = max(5, min(args.steps, 10))
+            xdt = time_workload(xw, xsteps, 2, device, parallel)
+            xr = xw.rooflines()
+            extra[xname] = {"workload": xw.name, "step": step_text(xw.name), "scenes_per_gpu": xbatch,
+                            "steps": xsteps, "ms_per_step": xdt / xsteps * 1e3, "scenes_per_s": xbatch * xsteps / xdt,
+                            "dtype": xw.dtype}
+            if xname == "backbone_infer" and xr.get("roofline") is not None:
+                extra[xname]["roofline_mfma_fused_sa"] = xr["roofline"]
+            del xw
+        line["extra"] = extra
+
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = wl.cpu_baseline()
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

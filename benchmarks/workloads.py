@@ -1,0 +1,521 @@
+"""Workloads of bench.py: the reference's training / inference iterations and the bare operator sequence, on
+synthetic scenes, plus the live (HIP-event) roofline legs and the CPU-baseline legs of the bench line."""
+import glob
+import hashlib
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from pdanet_amd.tuning import enable_tuned_gemms  # noqa: F401
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DEFAULT = "detector_train"
+
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
+F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (v_mfma_f32_32x32x2_f32) = the f32 vector peak
+# plain (non-packed) VALU lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  A ball-query
+# distance test is 7 VALU instructions (3 sub, 1 mul, 2 fma, 1 compare), none of them packable without losing
+# the reference's float expression, so the VALU bound is VALU_LANE_OPS / 7 tests per second.
+VALU_LANE_OPS = 256 * 4 * 16 * 2.4e9
+BALL_QUERY_VALU_PER_TEST = 7
+
+# ONCE PDA-SSD layer shapes at N_in = 16384:
+#   (centres M, points N, [(radius, nsample)], feature channels C)
+ONCE16K_LAYERS = [
+    dict(name="L0", M=16384, N=16384, scales=[(0.2, 16), (0.8, 32)], C=1, fps=None),
+    dict(name="L1", M=4096, N=16384, scales=[(0.8, 16), (1.6, 32)], C=64, fps=(16384, 4096)),
+    dict(name="L2", M=2048, N=4096, scales=[(1.6, 16), (4.8, 32)], C=128, fps=None),
+    dict(name="L5", M=1024, N=2048, scales=[(4.8, 16), (8.4, 32), (12.8, 64)], C=256, fps=None),
+]
+
+
+def _csrc_hash(*files):
+    """sha1 of the kernel sources a committed counter pass belongs to: a PMC record whose hash differs from the
+    sources in the tree is STALE (the kernel changed after the pass) and is not reported."""
+    h = hashlib.sha1()
+    for f in files:
+        with open(os.path.join(ROOT, "pdanet_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_record(kind, key, sources, prefix=False, by=None):
+    """Entry `key` of the newest profiles/r*_pmc/<kind>.json (kind = 'traffic' | 'mfma_util'), or None.  PMC
+    counters cannot be read from inside the process (rocprofv3 passes, tools/pmc_passes.sh), so the bench line
+    carries the committed record -- but only while the record's `csrc_sha1` still equals the hash of `sources`."""
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc", kind + ".json"))):
+        try:
+            doc = json.load(open(f))
+            sha = doc.get("csrc_sha1", {})
+            if any(sha.get(s) != _csrc_hash(s) for s in sources):
+                continue
+            for name, k in doc["kernels"].items():
+                if name == key or (prefix and name.startswith(key)):
+                    if by is None or best is None or k[by] > best[by]:
+                        best = k
+        except (OSError, ValueError, KeyError):
+            pass
+    return best
+
+
+def pmc_traffic(key, sources, prefix=False):
+    k = pmc_record("traffic", key, sources, prefix)
+    return None if k is None else k["hbm_bytes_per_launch_mean"]
+
+
+def fps_algorithmic_bytes(n, m):
+    return (m - 1) * n * 20 + m * 4  # SURVEY.md 8(d) / BASELINE.md section 2, per scene
+
+
+def ball_query_algorithmic_bytes(n, m, nsamples):
+    """SURVEY.md 8(d), per scene and per radius: ceil(M/256)*N*12 + M*12 + M*ns*4."""
+    return sum(-(-m // 256) * n * 12 + m * 12 + m * ns * 4 for ns in nsamples)
+
+
+class KernelTimers:
+    """HIP-event timing of this repo's own kernels at their Python entry points, on the stream they are launched
+    on (torch events record on the CURRENT stream, and the ops launch on the current stream -- for the D-FPS
+    prefetch that is the side stream of backbone._presample).  Active only while `record` is set."""
+
+    def _install_timers(self):
+        from pdanet_amd import pointnet2_utils as pu
+        wl = self
+        self.record = False
+        self.fps_events, self.bq_events, self.wgrad_events = [], [], []
+
+        def timed(orig, sink, describe):
+            def f(*a):
+                if not wl.record:
+                    return orig(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(*a)
+                e1.record()
+                sink.append((e0, e1) + describe(*a))
+                return out
+            f._pda_orig = orig
+            return f
+
+        def unwrap(fn):
+            return getattr(fn, "_pda_orig", fn)
+        ext = pu.pointnet2
+        ext.farthest_point_sampling_wrapper = timed(unwrap(ext.farthest_point_sampling_wrapper), self.fps_events,
+                                                    lambda b, n, m, *r: (b, n, m))
+        ext.ball_query_multi = timed(unwrap(ext.ball_query_multi), self.bq_events,
+                                     lambda b, n, m, radii, ns, *r: (b, n, m, tuple(radii), tuple(ns)))
+        ext.linear_wgrad = timed(unwrap(ext.linear_wgrad), self.wgrad_events,
+                                 lambda x, g, gw, gb, tokens, n_in, n_out: (tokens, n_in, n_out))
+
+    @staticmethod
+    def _mean_s(events):
+        ts = [e0.elapsed_time(e1) * 1e-3 for e0, e1 in events]
+        return sum(ts) / len(ts)
+
+    def roofline_fps(self):
+        """The D-FPS launch of the step (dominant sampling kernel): SURVEY 8(d) bytes / mean launch duration."""
+        if not self.fps_events:
+            return None
+        b, n, m = max((e[2:] for e in self.fps_events), key=lambda s: s[1] * s[2])
+        t = self._mean_s([e[:2] for e in self.fps_events if e[2:] == (b, n, m)])
+        alg = fps_algorithmic_bytes(n, m) * b
+        ach = alg / t / 1e9
+        kern = "fps_pruned_kernel" if 2048 <= n <= 65536 else "fps_reg_kernel"
+        return {"kernel": "%s (FPS %d->%d, %d scenes/launch)" % (kern, n, m, b), "bound": "hbm", "achieved": ach,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("pda::fps_pruned_kernel FPS %d->%d b%d" % (n, m, b), ["fps.hip"]),
+                "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg,
+                "compulsory_bytes_per_launch": (n * 16 + m * 4) * b,
+                "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene: the specified algorithm with no "
+                        "on-chip reuse) / kernel time.  The kernel keeps the scene on chip (exact spatial pruning "
+                        "skips no-op updates), so its real HBM traffic is the compulsory N*16+m*4 bytes per scene "
+                        "and it is bound by the latency of m-1 dependent arg-max rounds, not by HBM.  traffic = "
+                        "(2*FETCH_SIZE+WRITE_SIZE) KB per launch from the committed rocprofv3 --pmc passes "
+                        "(null when the kernel source changed since the pass)"}
+
+    def roofline_ball_query(self):
+        """The layer-0 ball-query launch (largest M*N of the step; both radii in one pass)."""
+        if not self.bq_events:
+            return None
+        b, n, m, radii, nss = max((e[2:] for e in self.bq_events), key=lambda s: s[1] * s[2])
+        t = self._mean_s([e[:2] for e in self.bq_events if e[2:] == (b, n, m, radii, nss)])
+        alg = ball_query_algorithmic_bytes(n, m, nss) * b
+        ach = alg / t / 1e9
+        tests = float(b) * n * m * len(radii)
+        peak_tests = VALU_LANE_OPS / BALL_QUERY_VALU_PER_TEST
+        return {"kernel": "ball query %dx%d, radii %s, nsample %s, %d scenes/launch" % (m, n, list(radii), list(nss), b),
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                "traffic": pmc_traffic("pda::ball_query %dx%d r%d b%d" % (m, n, len(radii), b), ["ball_query.hip"]),
+                "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg,
+                "distance_tests_per_launch": tests, "tests_per_s": tests / t,
+                "valu_bound_tests_per_s": peak_tests, "valu_frac": tests / t / peak_tests,
+                "note": "bytes per SURVEY 8(d) (xyz streamed once per 256 centres, per radius); tests = M*N per "
+                        "radius (the brute-force count -- a spatially binned kernel performs fewer and can exceed "
+                        "valu_frac 1); VALU bound = 256 CUs x 64 lanes x 2.4 GHz / 7 instructions per test"}
+
+    def roofline_wgrad(self):
+        """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
+        2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration."""
+        by = {}
+        for e in self.wgrad_events:
+            by.setdefault(e[2:], []).append(e[0].elapsed_time(e[1]) * 1e-3)
+        if not by:
+            return None
+        (t, ni, no), times = max(by.items(), key=lambda kv: sum(kv[1]))
+        avg = sum(times) / len(times)
+        flops = 2.0 * t * ni * no
+        total = sum(sum(v) for v in by.values())
+        steps = max(1, len(self.fps_events))          # one D-FPS launch per step
+        key = "pda::wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t)
+        util = pmc_record("mfma_util", "pda::wgrad_kernel", ["wgrad.hip"], prefix=True, by="launches")
+        return {"kernel": key[5:], "bound": "mfma", "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
+                "achieved": flops / avg / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": flops / avg / 1e12 / F32_MFMA_PEAK_TF, "traffic": pmc_traffic(key, ["wgrad.hip"]),
+                "avg_launch_ms": avg * 1e3,
+                "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); event-timed launch = split-K kernel + "
+                        "fixed-order second stage; all %d wgrad launches of a step: %.2f ms" % (
+                            sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
+
+
+class SamplingGroupingWorkload(KernelTimers):
+    """All sampling/grouping operator calls of one PDA-SSD backbone forward (ONCE-16k)."""
+
+    name = "once16k_b2_sampling_grouping"
+
+    def __init__(self, batch, n_points, device, rank):
+        from pdanet_amd import pointnet2_utils as pu, synth
+        self.pu = pu
+        self.B, self.N = batch, n_points
+        xyz = synth.batch_xyz(batch, n_points, config_id=2 + 10 * rank, dist="L")
+        self.xyz_np = xyz
+        self.xyz = torch.from_numpy(xyz).to(device)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.feats = {L["name"]: torch.randn(batch, L["C"], L["N"], generator=g).to(device)
+                      for L in ONCE16K_LAYERS}
+        self.dtype = "f32"
+        self._install_timers()
+
+    def begin(self):
+        self._install_timers()
+
+    def step(self):
+        pu = self.pu
+        xyz = self.xyz
+        out = 0
+        for L in ONCE16K_LAYERS:
+            pts = xyz[:, :L["N"]].contiguous() if L["N"] != xyz.shape[1] else xyz
+            if L["fps"] is not None:
+                idx = pu.furthest_point_sample(pts, L["M"])
+                new_xyz = pu.gather_operation(pts.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+            else:
+                new_xyz = pts[:, :L["M"]].contiguous()
+            idxs = pu.ball_query_multi([r for r, _ in L["scales"]], [ns for _, ns in L["scales"]], pts, new_xyz)
+            pts_t = pts.transpose(1, 2).contiguous()
+            for idx_s in idxs:
+                gx = pu.grouping_operation(pts_t, idx_s)
+                gf = pu.grouping_operation(self.feats[L["name"]], idx_s)
+                out = out + gx.numel() + gf.numel()
+            xyz = new_xyz if L["name"] != "L5" else xyz
+        return out
+
+    def rooflines(self):
+        return {"roofline": self.roofline_fps(), "roofline_ball_query": self.roofline_ball_query()}
+
+    def cpu_baseline(self, budget_s=20.0):
+        """The same operator sequence through the CPU oracle (kind 'port'), on scene 0, all cores."""
+        return sampling_grouping_cpu(self.xyz_np, None)
+
+
+def sampling_grouping_cpu(xyz_np, threads):
+    """FPS + ball queries + groupings of one ONCE-16k scene (SURVEY 8(d) CPU baseline) through the oracle with
+    `threads` OpenMP threads (None = all cores)."""
+    import oracle
+    ncores = oracle.num_threads()
+    nthreads = ncores if threads is None else threads
+    oracle.set_num_threads(nthreads)
+    xyz = np.ascontiguousarray(xyz_np[:1])
+    t0 = time.perf_counter()
+    cur = xyz
+    for L in ONCE16K_LAYERS:
+        pts = np.ascontiguousarray(cur[:, :L["N"]])
+        n = pts.shape[1]
+        if L["fps"] is not None:
+            temp = np.full((1, n), 1e10, np.float32)
+            idx = np.zeros((1, L["M"]), np.int32)
+            oracle.farthest_point_sampling_wrapper(1, n, L["M"], pts, temp, idx)
+            new_xyz = np.ascontiguousarray(pts[0][idx[0]][None])
+        else:
+            new_xyz = np.ascontiguousarray(pts[:, :L["M"]])
+        feats = np.zeros((1, L["C"], n), np.float32)
+        pts_t = np.ascontiguousarray(pts.transpose(0, 2, 1))
+        for r, ns in L["scales"]:
+            bq = np.zeros((1, L["M"], ns), np.int32)
+            oracle.ball_query_wrapper(1, n, L["M"], r, ns, new_xyz, pts, bq)
+            gx = np.empty((1, 3, L["M"], ns), np.float32)
+            oracle.group_points_wrapper(1, 3, n, L["M"], ns, pts_t, bq, gx)
+            gf = np.empty((1, L["C"], L["M"], ns), np.float32)
+            oracle.group_points_wrapper(1, L["C"], n, L["M"], ns, feats, bq, gf)
+        cur = new_xyz if L["name"] != "L5" else cur
+    dt = time.perf_counter() - t0
+    oracle.set_num_threads(ncores)
+    return dict(value=1.0 / dt, unit="scenes/s", cores=nthreads, kind="port",
+                sample="sampling/grouping operators only (FPS 16384->4096, 9 ball queries, 18 groupings at the "
+                       "ONCE-16k layer shapes) of 1 scene through oracle/libpda_oracle.so, %d OpenMP thread%s, "
+                       "%.2f s" % (nthreads, "" if nthreads == 1 else "s", dt))
+
+
+class BackboneWorkload(KernelTimers):
+    """PDA-SSD backbone (IASSD_Backbone, ONCE yaml) forward + backward on synthetic ONCE scenes.
+
+    One step = forward over `batch` scenes of `n_points` points in training mode (batch-stat
+    BatchNorm, as the reference trains) + backward of a scalar loss that touches every backbone
+    output the detection head consumes (centers_features, ctr_offsets, sa_ins_preds), so every
+    parameter receives a gradient.  No optimiser step: the head/loss/optimiser are the "next"
+    rows -- the metric here is the backbone fwd+bwd rate.
+    With world > 1 the model is wrapped in DDP (RCCL gradient all-reduce over xGMI).
+    """
+
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml"):
+        from pdanet_amd import synth
+        from pdanet_amd.backbone import build_backbone
+        self.B, self.N = batch, n_points
+        self.name = "once16k_b%d_backbone_fwd_bwd" % batch if n_points == 16384 else \
+            "once%d_b%d_backbone_fwd_bwd" % (n_points, batch)
+        self.device = device
+        self.cfg_name = cfg
+        from pdanet_amd import pointnet2_utils as _pu
+        self.dense_bf16 = bool(dense_bf16)
+        _pu.DENSE_BF16 = self.dense_bf16        # DESIGN.md "Dense-bf16 mode" (not torch.autocast); see begin()
+        self.dtype = "bf16 GEMMs (f32 accumulate) and GEMM-adjacent tensors; residual stream, statistics and kernel arithmetic f32" if dense_bf16 else "f32"
+        self.tuned = enable_tuned_gemms() if os.environ.get("PDA_NO_TUNED_GEMMS") != "1" else False
+        torch.manual_seed(1234)  # same initial weights on every rank
+        model, self.cfg = build_backbone(cfg)
+        self.model = model.to(device).train()
+        from pdanet_amd import parallel
+        self.ddp = parallel.wrap_ddp(self.model, device) if world > 1 else None
+        self.points_np = synth.batch_points(batch, n_points, config_id=2 + 10 * rank, dist="L")
+        self.points = torch.from_numpy(self.points_np).to(device)
+        self._install_timers()
+
+    def begin(self):
+        """Make this workload's process-wide switches current (several workloads run one after another in one
+        bench.py process: the headline and the `extra` timings)."""
+        from pdanet_amd import pointnet2_utils as _pu
+        _pu.DENSE_BF16 = self.dense_bf16
+        self._install_timers()
+
+    def rooflines(self):
+        return {"roofline": self.roofline_fps(), "roofline_ball_query": self.roofline_ball_query(),
+                "roofline_mfma": self.roofline_wgrad()}
+
+    @staticmethod
+    def loss_of(bd):
+        loss = bd['centers_features'].float().pow(2).mean() + bd['ctr_offsets'][:, 1:].pow(2).mean()
+        for p in bd['sa_ins_preds']:
+            if not isinstance(p, list):
+                loss = loss + p[..., 1:].float().pow(2).mean()
+        return loss
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        for p in self.model.parameters():
+            p.grad = None
+        bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
+        loss = self.loss_of(bd)
+        loss.backward()
+        return loss
+
+    def cpu_baseline(self, budget_s=30.0):
+        """Same step on the host cores: this repo's model code with the operator extension
+        replaced by the CPU oracle (kind 'port'), dense layers on torch CPU.  One scene pair is
+        too slow for a default run, so the sample is ONE step over ONE scene."""
+        import oracle
+        from pdanet_amd import pointnet2_utils as pu
+        from pdanet_amd.backbone import build_backbone
+
+        class Stub:
+            pass
+        stub = Stub()
+        for name in ["ball_query_wrapper", "ball_query_dilated_wrapper", "group_points_wrapper",
+                     "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
+                     "farthest_point_sampling_wrapper", "furthest_point_sampling_with_dist_wrapper",
+                     "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper"]:
+            def mk(fn):
+                return lambda *a: fn(*[x.numpy() if isinstance(x, torch.Tensor) else x for x in a])
+            setattr(stub, name, mk(getattr(oracle, name)))
+
+        def bq_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
+            for r, ns, idx in zip(radii, nsamples, idxs):
+                oracle.ball_query_wrapper(b, n, m, r, ns, new_xyz.numpy(), xyz.numpy(), idx.numpy())
+            return 1
+        stub.ball_query_multi = bq_multi
+        saved = pu.pointnet2
+        pu.pointnet2 = stub
+        try:
+            torch.manual_seed(1234)
+            model, _ = build_backbone(self.cfg_name)
+            model.train()
+            pts = torch.from_numpy(self.points_np[: self.N].copy())
+            nthreads = max(oracle.num_threads(), torch.get_num_threads())
+            t0 = time.perf_counter()
+            bd = model({'batch_size': 1, 'points': pts})
+            self.loss_of(bd).backward()
+            dt = time.perf_counter() - t0
+        finally:
+            pu.pointnet2 = saved
+        return dict(value=1.0 / dt, unit="scenes/s", cores=nthreads, kind="port",
+                    sample="1 step over 1 scene (scene 0 of the GPU batch, %d pts): this repo's backbone "
+                           "with the extension replaced by oracle/libpda_oracle.so and dense layers on "
+                           "torch CPU, fwd+bwd, %.1f s" % (self.N, dt))
+
+
+class BackboneInferWorkload(BackboneWorkload):
+    """BASELINE configs[1] literally: PDA-SSD backbone FORWARD (eval BatchNorm, no_grad) with
+    the fused SA-scale kernel on layers 0 and 5."""
+
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False):
+        super().__init__(batch, n_points, device, rank, world, dense_bf16=dense_bf16)
+        from pdanet_amd import fused_ops
+        self.fused_ops = fused_ops
+        self.name = self.name.replace("fwd_bwd", "fwd_eval_fused")
+        self.model.eval()
+        fused_ops.enable_fused(self.model)
+        self.ddp = None
+        self.sa_events = []
+
+    def step(self):
+        self.fused_ops.PROFILE = self.sa_events if self.record else None
+        with torch.no_grad():
+            bd = self.model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
+        self.fused_ops.PROFILE = None
+        return bd['centers_features']
+
+    def rooflines(self):
+        return {"roofline": self.roofline_sa_mlp(), "roofline_fps": self.roofline_fps(),
+                "roofline_ball_query": self.roofline_ball_query()}
+
+    def roofline_sa_mlp(self):
+        """Dominant fused kernel = the launch shape with the largest mean duration."""
+        by = {}
+        for e0, e1, flops, dims, ns in self.sa_events:
+            by.setdefault((dims, ns), []).append((e0.elapsed_time(e1) * 1e-3, flops))
+        if not by:
+            return None
+        stats = {k: (sum(t for t, _ in v) / len(v), v[0][1]) for k, v in by.items()}
+        (dims, ns), (t, flops) = max(stats.items(), key=lambda kv: kv[1][0])
+        l5 = {k: v for k, v in stats.items() if k[0][0] > 100}
+        l5_t, l5_f = sum(v[0] for v in l5.values()), sum(v[1] for v in l5.values())
+        peak = F32_MFMA_PEAK_TF
+        util = pmc_record("mfma_util", "pda::sa_mlp_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
+        return {"kernel": "sa_mlp_kernel %s ns=%d (%d scenes/launch)" % ("->".join(map(str, dims)), ns, self.B),
+                "bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / peak, "traffic": None, "avg_launch_ms": t * 1e3,
+                "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
+                "note": "f32-input MFMA (v_mfma_f32_32x32x2_f32); layer 5, all scales: %.1f GFLOP in %.3f ms = "
+                        "%.1f TFLOP/s = %.1f %% of peak" % (l5_f / 1e9, l5_t * 1e3, l5_f / l5_t / 1e12,
+                                                            100 * l5_f / l5_t / 1e12 / peak) if l5_t > 0 else ""}
+
+    def cpu_baseline(self, budget_s=30.0):
+        base = super().cpu_baseline(budget_s)
+        base["sample"] += " (training-mode fwd+bwd step; the inference forward alone is ~1/3 of it)"
+        return base
+
+
+class TrainStepWorkload(BackboneWorkload):
+    """Forward + backward + clip_grad_norm_(10) + adam_onecycle step (pdanet_amd/optimization.py,
+    csrc/optim.hip) -- the iteration of tools/train_utils/train_utils.py:34-60 around the backbone.
+    `kitti_train_bf16`: KITTI yaml, 4 scenes per GPU, dense-bf16 mode (pointnet2_utils.DENSE_BF16;
+    operators, activations and statistics stay fp32)."""
+
+    OPTIM = dict(OPTIMIZER="adam_onecycle", LR=0.01, WEIGHT_DECAY=0.01, MOMS=[0.95, 0.85], PCT_START=0.4,
+                 DIV_FACTOR=10, GRAD_NORM_CLIP=10)   # once/kitti PDA-SSD.yaml OPTIMIZATION
+
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml", dataset="once"):
+        from pdanet_amd import optimization, parallel, synth
+        super().__init__(batch, n_points, device, rank, 1, dense_bf16=dense_bf16, cfg=cfg)
+        if dataset != "once":
+            self.points_np = synth.batch_points(batch, n_points, config_id=3 + 10 * rank, dist="L", dataset=dataset)
+            self.points = torch.from_numpy(self.points_np).to(device)
+        self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
+        self.opt = optimization.build_optimizer(self.model, self.OPTIM)     # flat buffers BEFORE DDP
+        self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.OPTIM)
+        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
+        self.it = 0
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        self.sched.step(self.it)
+        self.opt.zero_grad(set_to_none=self.ddp is None)    # DDP copies its reduced buckets into the flat-buffer views
+        bd = model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
+        loss = self.loss_of(bd)
+        loss.backward()
+        self.opt.step()
+        self.it += 1
+        return loss
+
+
+class DetectorTrainWorkload(TrainStepWorkload):
+    """The whole training iteration of PDA-SSD on synthetic scenes + ground truth: IASSD detector
+    (backbone + IASSD_Head: target assignment, all configured losses) forward, backward, gradient
+    clipping and the adam_onecycle step -- tools/train_utils/train_utils.py:34-60 with model_func =
+    model_fn_decorator (pcdet/models/__init__.py).  No host synchronisation inside the step."""
+
+    def __init__(self, batch, n_points, device, rank, world, dense_bf16=False, cfg="once_pda_ssd.yaml", dataset="once"):
+        from pdanet_amd import detector, optimization, parallel, synth
+        BackboneWorkload.__init__(self, batch, n_points, device, rank, 1, dense_bf16=dense_bf16, cfg=cfg)
+        self.points_np = synth.batch_points(batch, n_points, config_id=(2 if dataset == "once" else 3) + 10 * rank,
+                                            dist="L", dataset=dataset)
+        self.points = torch.from_numpy(self.points_np).to(device)
+        self.gt = torch.from_numpy(synth.gt_boxes(self.points_np, batch, config_id=2 + 10 * rank, dataset=dataset)).to(device)
+        torch.manual_seed(1234)
+        model, self.cfg = detector.build_detector(cfg)
+        self.model = model.to(device).train()
+        self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
+        self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
+        self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
+        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
+        self.it = 0
+
+    def cpu_baseline(self, budget_s=30.0):
+        base = super().cpu_baseline(budget_s)
+        base["sample"] += (" -- the BACKBONE fwd+bwd of the iteration only (the head's target assignment and losses "
+                           "and the optimizer step have no CPU form in this repo; they are ~6 %% of the GPU step)")
+        return base
+
+    def step(self):
+        model = self.ddp if self.ddp is not None else self.model
+        self.sched.step(self.it)
+        self.opt.zero_grad(set_to_none=self.ddp is None)    # DDP copies its reduced buckets into the flat-buffer views
+        ret, tb, _ = model({'batch_size': self.B, 'points': self.points, 'gt_boxes': self.gt, 'inputs_resident': True})
+        ret['loss'].backward()
+        self.opt.step()
+        self.it += 1
+        self.tb = tb
+        return ret['loss']
+
+
+def create(name, batch, n_points, device, rank, world):
+    if name == "sampling_grouping":
+        return SamplingGroupingWorkload(batch, n_points, device, rank)
+    if name == "detector_train":
+        return DetectorTrainWorkload(batch, n_points, device, rank, world)
+    if name == "kitti_detector_train_bf16":
+        return DetectorTrainWorkload(batch, n_points, device, rank, world, dense_bf16=True, cfg="kitti_pda_ssd.yaml",
+                                     dataset="kitti")
+    if name == "train_step":
+        return TrainStepWorkload(batch, n_points, device, rank, world)
+    if name == "kitti_train_bf16":
+        return TrainStepWorkload(batch, n_points, device, rank, world, dense_bf16=True, cfg="kitti_pda_ssd.yaml",
+                                 dataset="kitti")
+    if name == "backbone_infer":
+        return BackboneInferWorkload(batch, n_points, device, rank, world)
+    if name == "backbone_infer_bf16":
+        return BackboneInferWorkload(batch, n_points, device, rank, world, dense_bf16=True)
+    if name == "backbone":
+        return BackboneWorkload(batch, n_points, device, rank, world, dense_bf16=False)
+    if name == "backbone_bf16":
+        return BackboneWorkload(batch, n_points, device, rank, world, dense_bf16=True)
+    raise ValueError("unknown workload %r" % name)

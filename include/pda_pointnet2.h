@@ -83,6 +83,14 @@ int pda_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, 
 int pda_ball_query_dilated(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n,
                            int m, float max_radius, float min_radius, int nsample,
                            pda_stream_t stream);
+/* stands where `ellipsoid_query` (pointnet2_api.cpp:16; ellipsoid_query.cpp:13-76, kernel
+ * ellipsoid_query_gpu.cu) stands in the reference's module, so the boundary's name set is complete.
+ * No PDA-SSD yaml reaches it (its only call on the PDA path is commented out,
+ * pointnet2_utils.py:586-587; the "Ellipsoid" SA class uses the spherical ball query):
+ * the entry point validates nothing, launches nothing and returns PDA_ERR_UNSUPPORTED with a message;
+ * the Python mirror raises.  idx would be (b,m,nsample), allocated by the caller here. */
+int pda_ellipsoid_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
+                        float e1, float e2, float e3, int nsample, pda_stream_t stream);
 /* MI355X extension (no reference counterpart): up to 3 radii over the SAME centres and
  * points in one pass -- the multi-scale groupers call ball_query once per scale
  * (pointnet2_modules.py:1657).  idx[i] is (b,m,nsamples[i]); results are identical to

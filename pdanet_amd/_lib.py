@@ -28,6 +28,7 @@ SIGNATURES = {
     "pda_gather_points_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pda_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "pda_ball_query_dilated": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
+    "pda_ellipsoid_query": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp],
     "pda_ball_query_multi": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i,
                              ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int32), _vp],
     "pda_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

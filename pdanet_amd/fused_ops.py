@@ -39,7 +39,9 @@ class FusedSAMlp:
         bns = [m for m in seq if isinstance(m, torch.nn.BatchNorm2d)]
         if len(convs) != 3 or len(bns) != 3:
             return None
-        key = tuple((c.weight._version, c.weight.data_ptr()) for c in convs) + \
+        # PARAM_EPOCH: the flat-buffer optimizer and the BN kernels' running-statistics updates write through raw
+        # pointers, which moves neither _version nor data_ptr (eval -> train k steps -> eval must re-pack)
+        key = (_lib.PARAM_EPOCH[0],) + tuple((c.weight._version, c.weight.data_ptr()) for c in convs) + \
             tuple((b.weight._version, b.bias._version, b.running_mean._version, b.running_var._version) for b in bns)
         hit = self.cache.get(i)
         if hit is not None and hit["key"] == key:

@@ -7,8 +7,9 @@ pointnet2`` unchanged.  Each wrapper validates like the reference's CHECK_INPUT
 (ball_query.cpp:17-29: CUDA tensor + contiguous), launches the HIP kernel on torch's CURRENT
 stream through the C ABI (include/pda_pointnet2.h) and returns what the reference returns
 (1, 2 for the with-dist FPS, None for the interpolate trio).  Where the reference prints and
-calls exit(-1), this raises.  ``ellipsoid_query`` is not reached by PDA-SSD.yaml (SURVEY.md 2.1) and is not provided;
-``chamfer_forward/backward`` are.
+calls exit(-1), this raises.  ``ellipsoid_query`` is not reached by PDA-SSD.yaml: the name exists so the
+module's name set equals the reference's, and raises PdaError (PDA_ERR_UNSUPPORTED).  ``chamfer_forward/backward``
+ are implemented.
 """
 import ctypes
 
@@ -67,6 +68,16 @@ def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz
     _call("pda_ball_query_dilated", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32),
           _chk(idx, "idx", I32), b, n, m, float(max_radius), float(min_radius), nsample)
     return 1
+
+
+def ellipsoid_query(new_xyz, xyz, e1, e2, e3, nsample):
+    """pointnet2_api.cpp:16 / ellipsoid_query.cpp:13: allocates and returns idx (b, m, nsample) in the reference.  Not
+    on the PDA-SSD path and not implemented: pda_ellipsoid_query returns PDA_ERR_UNSUPPORTED and this raises PdaError."""
+    b, m, n = new_xyz.shape[0], new_xyz.shape[1], xyz.shape[1]
+    idx = torch.zeros((b, m, nsample), dtype=I32, device=new_xyz.device)
+    _call("pda_ellipsoid_query", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32), _chk(idx, "idx", I32),
+          b, n, m, float(e1), float(e2), float(e3), int(nsample))
+    return idx
 
 
 def ball_query_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
@@ -221,12 +232,21 @@ def _io(t, name):
     return _chk(t, name, F32), 0
 
 
+def _buffers_written(running):
+    """The kernel about to be launched updates BatchNorm running statistics through raw pointers: tensor version
+    counters do not move, so every cache of tensors derived from them (eval-BN folded into convolutions, the packed
+    weights + scale/shift of the fused SA kernel) must see a new _lib.PARAM_EPOCH."""
+    if running is not None:
+        _lib.PARAM_EPOCH[0] += 1
+
+
 def bn_relu_fwd(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum):
     """MI355X extension: training-mode BatchNorm + ReLU over the last dim (csrc/bn_relu.hip).  x / y fp32, or bf16 where
     they sit next to a bf16 GEMM (dense-bf16 mode)."""
     _numel_ok(x, rows * c, "x"); _numel_ok(y, rows * c, "y"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
     rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
     rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _buffers_written(rm)
     if x.dtype == F32 and y.dtype == F32:
         _call("pda_bn_relu_fwd", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv,
               _chk(y, "y", F32), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c,
@@ -258,6 +278,7 @@ def bn_relu_max_pool_fwd(x, gamma, beta, running_mean, running_var, out, arg, me
     _numel_ok(x, groups * ns * c, "x"); _numel_ok(out, groups * c, "out"); _numel_ok(arg, groups * c, "arg"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
     rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
     rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _buffers_written(rm)
     xp, xb = _io(x, "x")
     _call("pda_bn_relu_max_pool_fwd", x, xp, xb, _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv, _chk(out, "out", F32),
           _chk(arg, "arg", torch.uint8), _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), groups, ns, c,
@@ -356,6 +377,7 @@ def densitynet_fwd(x, params, y, stats, scratch, running, n, eps, momentum):
     running: [rm1, rv1, rm2, rv2, rm3, rv3] or None."""
     _numel_ok(x, n, "x"); _numel_ok(y, n, "y")
     r = [None] * 6 if running is None else [_chk(t, "running", F32) for t in running]
+    _buffers_written(running)
     _call("pda_densitynet_fwd", x, _chk(x, "x", F32), _chk(params, "params", F32), _chk(y, "y", F32), _chk(stats, "stats", F32),
           _chk(scratch, "scratch", torch.uint8), *r, n, float(eps), float(momentum))
     return 1

@@ -62,8 +62,14 @@ def test_mirror_module_matches_reference_names():
                  "group_points_grad_wrapper", "gather_points_wrapper", "gather_points_grad_wrapper",
                  "farthest_point_sampling_wrapper", "furthest_point_sampling_with_dist_wrapper",
                  "three_nn_wrapper", "three_interpolate_wrapper", "three_interpolate_grad_wrapper",
-                 "chamfer_forward", "chamfer_backward"]:
+                 "chamfer_forward", "chamfer_backward", "ellipsoid_query"]:
         assert callable(getattr(ext, name))
+
+
+def test_ellipsoid_query_is_an_explicit_unsupported_entry(lib):
+    """pointnet2_api.cpp:16: the name is part of the boundary; no PDA-SSD yaml reaches it, the C ABI says so."""
+    st = lib.pda_ellipsoid_query(None, None, None, 1, 8, 8, ctypes.c_float(1), ctypes.c_float(2), ctypes.c_float(1), 4, None)
+    assert st == 3 and b"ellipsoid_query" in lib.pda_last_error()
 
 
 def test_ops_refuse_cpu_tensors():

@@ -19,23 +19,65 @@ def _setup(cfg, dataset, B=2, N=4096):
     return model, opt, sched, bd
 
 
-@pytest.mark.parametrize("cfg,dataset", [("once_pda_ssd.yaml", "once"), ("kitti_pda_ssd.yaml", "kitti")])
-def test_train_iterations_reduce_the_loss(cfg, dataset):
+# Iteration-0 loss of the setup above, identical to the last bit on four different MI355X boxes in rounds 1-2
+# (GPUTEST_r01.json, gpurun_out/hang.log, gpurun_out/r02_trace.log): the forward pass has no float atomics and
+# is deterministic.  rel=1e-4 leaves room for a different library-GEMM heuristic on another ROCm build.
+PINNED_FIRST_LOSS = {"once": 29.138835906982422, "kitti": 161.17782592773438}
+CASES = [("once_pda_ssd.yaml", "once"), ("kitti_pda_ssd.yaml", "kitti")]
+
+
+def _iteration(model, opt, sched, bd, it):
+    """tools/train_utils/train_utils.py:34-64: scheduler step, zero_grad, forward, backward, clip + optimizer step."""
+    sched.step(it)
+    opt.zero_grad()
+    ret, tb, _ = model(bd())
+    ret['loss'].backward()
+    return ret, tb
+
+
+@pytest.mark.parametrize("cfg,dataset", CASES)
+def test_first_training_iteration_is_pinned(cfg, dataset):
+    """Deterministic properties of ONE iteration (train_utils.py:34-64): pinned loss, every parameter has a finite
+    gradient, the target assignment found positives, the clipped step moved the trained parameters and left the
+    never-trained in_proj_* alone."""
+    model, opt, sched, bd = _setup(cfg, dataset)
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    ret, tb = _iteration(model, opt, sched, bd, 0)
+    missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
+    assert not missing, missing
+    assert float(tb['center_pos_num']) > 0 and float(tb['sa1_pos_num']) > 0
+    assert float(ret['loss'].detach()) == pytest.approx(PINNED_FIRST_LOSS[dataset], rel=1e-4)
+    gnorm = torch.sqrt(sum(p.grad.double().pow(2).sum() for p in model.parameters()))
+    opt.step()
+    assert float(opt.total_norm) == pytest.approx(float(gnorm), rel=1e-4)
+    moved = {n: (p.detach() - before[n]).abs().max().item() for n, p in model.named_parameters()}
+    for n, d in moved.items():
+        if "in_proj" in n:
+            assert d == 0.0, n
+        else:
+            assert np.isfinite(d), n
+            # Adam's first step moves a parameter by at most lr (plus the decoupled decay lr*wd*|p|)
+            assert d <= opt.lr * (1.0 + 0.01 * before[n].abs().max().item()) * 1.001, (n, d)
+    assert sum(d > 0 for d in moved.values()) > 200
+
+
+@pytest.mark.parametrize("cfg,dataset", CASES)
+def test_training_learns_over_40_iterations(cfg, dataset):
+    """Round 1 asserted `loss[5] < loss[0]`, which is a coin flip: from the first backward on the trajectories of
+    two runs differ (float-atomic gradient sums -> Adam's sign-like first steps -> a different top-k centre set), and
+    `center_loss_cls` -- weight 1, normalised by a positive count of a few dozen centres -- swings 129 -> 28 -> 47 ->
+    60 -> 34 in the first iterations (KITTI; gpurun_out/r02_trace.log, recorded in DESIGN.md).  Over 40 iterations
+    every recorded run falls 161 -> <4 (KITTI) and 29 -> <3.5 (ONCE); assert a property with a wide margin."""
     model, opt, sched, bd = _setup(cfg, dataset)
     losses = []
-    for it in range(6):
-        sched.step(it)
-        opt.zero_grad()
-        ret, tb, _ = model(bd())
-        ret['loss'].backward()
-        if it == 0:
-            missing = [n for n, p in model.named_parameters() if p.grad is None or not torch.isfinite(p.grad).all()]
-            assert not missing, missing
-            assert float(tb['center_pos_num']) > 0 and float(tb['sa1_pos_num']) > 0
+    for it in range(40):
+        ret, _ = _iteration(model, opt, sched, bd, it)
         opt.step()
-        losses.append(float(ret['loss']))
+        losses.append(ret['loss'].detach())
+    losses = [float(x) for x in torch.stack(losses).cpu()]
     assert all(np.isfinite(losses)), losses
-    assert losses[-1] < losses[0], losses
+    assert min(losses[-10:]) < 0.5 * losses[0], losses
+    assert float(np.mean(losses[-10:])) < float(np.mean(losses[:10])), losses
 
 
 def test_state_dict_keys_follow_the_reference_detector():

@@ -84,3 +84,34 @@ def test_fused_weight_update_invalidates_cache():
         c = layer(xyz, feats, None)[1]
     assert not torch.allclose(a, b)
     assert float((b - c).abs().max()) <= 2e-4 * max(1.0, float(c.abs().max()))
+
+
+def test_fused_cache_sees_raw_pointer_updates():
+    """eval(fused) -> k training steps of the flat-buffer optimizer -> eval(fused) must equal eval(unfused).
+    FlatAdamOneCycle.step and the BN+ReLU kernels' running-statistics updates write through raw pointers: neither
+    _version nor data_ptr of the conv / BN tensors moves, only _lib.PARAM_EPOCH does."""
+    from pdanet_amd import synth, fused_ops, optimization
+    xyz = torch.from_numpy(synth.batch_xyz(2, 1024, config_id=8)).cuda()
+    feats = torch.randn(2, 1, 1024, device="cuda", generator=torch.Generator("cuda").manual_seed(4))
+    layer = make_layer(1, [[16, 16, 32]], [2.0], [16], 256)
+    fused_ops.enable_fused(layer)
+    with torch.no_grad():
+        a = layer(xyz, feats, None)[1].clone()
+    assert layer.fused.cache
+    opt = optimization.FlatAdamOneCycle(layer, wd=0.01, grad_norm_clip=10, lr=1e-2, mom=0.9)
+    layer.train()
+    for _ in range(3):
+        opt.zero_grad()
+        layer(xyz, feats, None)[1].pow(2).mean().backward()
+        opt.step()
+    # a training forward WITHOUT an optimizer step (BN recalibration) must invalidate the cache as well
+    with torch.no_grad():
+        layer(xyz, feats * 3.0 + 1.0, None)
+    layer.eval()
+    with torch.no_grad():
+        b = layer(xyz, feats, None)[1].clone()
+        assert not layer.fused.unsupported
+        fused_ops.enable_fused(layer, False)
+        c = layer(xyz, feats, None)[1]
+    assert not torch.allclose(a, b)
+    assert float((b - c).abs().max()) <= 2e-4 * max(1.0, float(c.abs().max()))

@@ -2,7 +2,7 @@
 iterations and whether every value stayed finite.  Usage (MI355X): PYTHONPATH=. python tools/soak_train.py"""
 import sys, time, torch
 sys.path.insert(0, '.')
-from pdanet_amd import bench_workloads as bw
+from benchmarks import workloads as bw
 dev = torch.device('cuda:0')
 for name, batch in (('kitti_detector_train_bf16', 4), ('detector_train', 2)):
     wl = bw.create(name, batch, 16384, dev, 0, 1)
