@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -94,7 +94,8 @@ SIGNATURES = {
     "pda_stack_three_interpolate": [_vp, _vp, _vp, _vp, _i, _i, _vp],
     "pda_stack_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _vp],
 }
-INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads"]
+INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads",
+                "pda_fps_coop_timeouts", "pda_debug_fps_spin_limit"]
 
 _LIB = None
 
@@ -129,6 +130,10 @@ def load():
     lib.pda_fp_contract_mode.restype = _i
     lib.pda_opt_n_threads.argtypes = [_i]
     lib.pda_opt_n_threads.restype = _i
+    lib.pda_fps_coop_timeouts.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), _i]
+    lib.pda_fps_coop_timeouts.restype = _i
+    lib.pda_debug_fps_spin_limit.argtypes = [_i]
+    lib.pda_debug_fps_spin_limit.restype = _i
     if lib.pda_abi_version() != ABI_VERSION:
         raise PdaError("libpda_pointnet2.so ABI %d != binding ABI %d: rebuild"
                        % (lib.pda_abi_version(), ABI_VERSION))

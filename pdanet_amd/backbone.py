@@ -96,6 +96,10 @@ class IASSD_Backbone(nn.Module):
             plan.append(i)
         if not plan or not xyz.is_cuda:
             return {}
+        if xyz.shape[1] > 24576:
+            # the multi-workgroup FPS form (csrc/fps.hip) wants its K workgroups per scene resident together: keep
+            # it on the main stream, in program order, instead of racing other kernels for CUs on a side stream
+            return {}
         if self._side_stream is None or self._side_stream.device != xyz.device:
             self._side_stream = torch.cuda.Stream(device=xyz.device)
         main = torch.cuda.current_stream(xyz.device)

@@ -169,8 +169,20 @@ __device__ unsigned long long g_fps_stats[4];  // [0] wave-scans, [1] wave-round
 // (launch epoch, round)).  Each workgroup then reduces the K records with the same total order, so
 // all of them continue with the same sample.  Requires the K workgroups of a scene to be resident
 // together (host: grid <= 256 workgroups); every poll loop is bounded (FPS_SPIN_LIMIT).
+//
+// Failure model.  The exchange needs the K workgroups of a scene to be resident together.  The host sizes every
+// launch to what the device holds at once (launch_fps: grid <= CUs x 1 workgroup), so a workgroup can only be
+// late -- behind another stream's kernel that occupies its CU -- never absent; the polls are bounded all the same
+// (g_fps_spin_limit polls of ~0.1 us).  A timeout is neither silent nor fatal: the workgroup records the launch
+// epoch in g_fps_fail[region][scene], counts it in g_fps_fail_total and stops; fps_recover_kernel, launched behind
+// every cooperative launch on the same stream, finds the mark and recomputes that scene with the streaming
+// algorithm (temp re-filled with 1e10, the entry contract), so idx/temp are the exact result either way and no
+// unwritten index ever reaches a gather.  pda_fps_coop_timeouts() reports the count to the host.
 constexpr int FPS_XBUF_REGIONS = 4, FPS_XBUF_SCENES = 64, FPS_MAX_K = 4, FPS_SPIN_LIMIT = 1 << 20;
 __device__ unsigned long long g_fps_xbuf[FPS_XBUF_REGIONS * FPS_XBUF_SCENES * 2 * FPS_MAX_K * 5];
+__device__ int g_fps_spin_limit = FPS_SPIN_LIMIT;
+__device__ unsigned int g_fps_fail[FPS_XBUF_REGIONS * FPS_XBUF_SCENES];   // launch epoch of a timed-out exchange, per scene
+__device__ unsigned long long g_fps_fail_total;                            // workgroups that ever timed out
 
 template <int P, bool COOP>
 __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __restrict__ xyz_all,
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
     int32_t* __restrict__ idx = idx_all + (size_t)scene * m;
     const float INF = __builtin_inff();
     if (t == 0) failflag = 0;
+    const int spin_limit = COOP ? g_fps_spin_limit : 0;
 
     // ---- 1. scene bounding box ---------------------------------------------------------
     float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
@@ -443,7 +456,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
                         ok = (uint32_t)(gv >> 32) == tag;
                     }
                     if (__ballot(!ok) == 0ull) break;
-                    if (spin > FPS_SPIN_LIMIT) { failed = true; break; }
+                    if (spin >= spin_limit) { failed = true; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 const int pay = (int)(uint32_t)gv;
@@ -455,14 +468,19 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
                 const uint32_t tq = lane < K ? f1 : 0xffffffffu;
                 const float gmax = row0_max_f32(vq);
                 const uint32_t gT = row0_min_u32(vq == gmax ? tq : 0xffffffffu);
-                if (failed) { if (lane == 0) failflag = 1; }
+                if (failed && lane == 0) {
+                    failflag = 1;
+                    __hip_atomic_store(&g_fps_fail[(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + scene], epoch,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    atomicAdd(&g_fps_fail_total, 1ull);
+                }
                 if (lane < K && vq == gmax && tq == gT)
                     cand[1][0] = make_float4(__builtin_bit_cast(float, f2), __builtin_bit_cast(float, f3),
                                              __builtin_bit_cast(float, f4), __builtin_bit_cast(float, gT));
             }
         }
         lds_barrier();
-        if (COOP && failflag) break;  // an exchange timed out: give up (bounded), outputs are invalid
+        if (COOP && failflag) break;  // an exchange timed out: stop (bounded); fps_recover_kernel redoes this scene
         const float4 win = cand[1][0];
         x1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.x)));
         y1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, win.y)));
@@ -477,19 +495,12 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
 }
 
 template <bool WITH_DIST>
-__global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __restrict__ data_all,
-                                                                  float* __restrict__ temp_all,
-                                                                  int32_t* __restrict__ idx_all, int n,
-                                                                  int m, int L) {
-    __shared__ uint2 slots[2][FPS_WAVES];
+__device__ __forceinline__ void fps_stream_scene(const float* __restrict__ data, float* __restrict__ temp,
+                                                 int32_t* __restrict__ idx, int n, int m, int L, uint2 (*slots)[FPS_WAVES]) {
     const int t = threadIdx.x;
     const int lane = lane_id();
     const int w = wave_id();
     const int nwaves = (int)(blockDim.x >> 6);
-    const float* __restrict__ data = data_all + (size_t)blockIdx.x * n * (WITH_DIST ? (size_t)n : 3);
-    float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
-    int32_t* __restrict__ idx = idx_all + (size_t)blockIdx.x * m;
-
     int old = 0;
     if (t == 0) idx[0] = 0;
     for (int j = 1; j < m; ++j) {
@@ -512,6 +523,32 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __
         old = fps_block_argmax(best, T, slots[j & 1], nwaves, w, lane, L);
         if (t == 0) idx[j] = old;
     }
+}
+
+template <bool WITH_DIST>
+__global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __restrict__ data_all,
+                                                                  float* __restrict__ temp_all,
+                                                                  int32_t* __restrict__ idx_all, int n,
+                                                                  int m, int L) {
+    __shared__ uint2 slots[2][FPS_WAVES];
+    fps_stream_scene<WITH_DIST>(data_all + (size_t)blockIdx.x * n * (WITH_DIST ? (size_t)n : 3),
+                                temp_all + (size_t)blockIdx.x * n, idx_all + (size_t)blockIdx.x * m, n, m, L, slots);
+}
+
+// Behind every cooperative launch, same stream, one workgroup per scene: returns at once unless an exchange of
+// that launch timed out for its scene; then it recomputes the scene from scratch with the streaming algorithm.
+__global__ __launch_bounds__(FPS_THREADS) void fps_recover_kernel(const float* __restrict__ xyz_all,
+                                                                   float* __restrict__ temp_all,
+                                                                   int32_t* __restrict__ idx_all, int n, int m,
+                                                                   int L, uint32_t epoch) {
+    __shared__ uint2 slots[2][FPS_WAVES];
+    unsigned int* mark = &g_fps_fail[(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + blockIdx.x];
+    if (__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return;   // wave-uniform
+    float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
+    for (int k = threadIdx.x; k < n; k += FPS_THREADS) temp[k] = 1e10f;   // the entry contract (pointnet2_utils.py:26);
+    // thread t re-reads only the elements it wrote itself (same stride), so no barrier is needed before the scan
+    fps_stream_scene<false>(xyz_all + (size_t)blockIdx.x * n * 3, temp, idx_all + (size_t)blockIdx.x * m, n, m, L, slots);
+    if (threadIdx.x == 0) __hip_atomic_store(mark, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // pointnet2_stack: stack_farthest_point_sampling_kernel (pointnet2_stack/src/sampling_gpu.cu:188-318).  Per-scene
@@ -557,6 +594,15 @@ static int ilog2(int v) {
     return l;
 }
 
+// Workgroups of fps_pruned_kernel<16, true> the current device keeps resident at once.
+static int coop_resident_workgroups() {
+    int dev = 0, cus = 0, per_cu = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fps_pruned_kernel<16, true>, FPS_THREADS, 0) != hipSuccess) return 0;
+    return cus * std::min(per_cu, 1);
+}
+
 static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* idx, int b, int n, int m,
                       hipStream_t stream, const char* what) {
     PDA_REQUIRE(b >= 0 && n >= 0, "%s: negative size (b=%d n=%d)", what, b, n);
@@ -583,17 +629,24 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
     static const int no_coop = getenv("PDA_FPS_NO_COOP") ? atoi(getenv("PDA_FPS_NO_COOP")) : 0;
     // (16384, 24576] stays on the single-workgroup register kernel: 6.3 ms vs 7.7-9.0 ms cooperative
     if (!no_prune && !no_coop && n > 24 * FPS_THREADS && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
-        // K workgroups per scene, all resident together: at most 256/K (and 64) scenes per launch
+        // K workgroups per scene, all resident together: a launch holds at most what the device admits at once
+        // (one 1024-lane workgroup per CU for this kernel; the occupancy query only confirms >= 1) and 64 scenes
         static std::atomic<uint32_t> epoch_counter{1};
+        static const int resident = coop_resident_workgroups();
         const int K = divup(n, 16384);
-        const int chunk = std::min(FPS_XBUF_SCENES, 256 / K);
-        for (int s0 = 0; s0 < b; s0 += chunk) {
-            const int nb = std::min(chunk, b - s0);
-            const uint32_t epoch = epoch_counter.fetch_add(1) & 0x7fffu;
-            hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
-                               data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
-        }
-        return check_launch(what);
+        const int chunk = std::min(FPS_XBUF_SCENES, resident / K);
+        if (chunk >= 1) {
+            for (int s0 = 0; s0 < b; s0 += chunk) {
+                const int nb = std::min(chunk, b - s0);
+                uint32_t epoch = epoch_counter.fetch_add(1) & 0x7fffu;
+                if (epoch == 0) epoch = epoch_counter.fetch_add(1) & 0x7fffu;   // 0 = "no failure" in g_fps_fail
+                hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
+                                   data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
+                hipLaunchKernelGGL(fps_recover_kernel, dim3(nb), block, 0, stream, data + (size_t)s0 * n * 3,
+                                   temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, epoch);
+            }
+            return check_launch(what);
+        }   // a device too small to hold the K workgroups of one scene: streaming kernel below
     }
 #define PDA_FPS_CASE(PP)                                                                          \
     hipLaunchKernelGGL(fps_reg_kernel<PP>, grid, block, 0, stream, data, temp, idx, n, m, L)
@@ -617,6 +670,33 @@ PDA_API int pda_debug_fps_stats(unsigned long long* out, int reset) {
     return 0;
 }
 #endif
+
+PDA_API int pda_fps_coop_timeouts(unsigned long long* total, int reset) {
+    PDA_REQUIRE(total != nullptr, "pda_fps_coop_timeouts: null pointer");
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyFromSymbol(total, HIP_SYMBOL(pda::g_fps_fail_total), sizeof(unsigned long long)) != hipSuccess) {
+        pda::set_error("pda_fps_coop_timeouts: %s", hipGetErrorString(hipGetLastError()));
+        return PDA_ERR_LAUNCH;
+    }
+    if (reset) {
+        const unsigned long long z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(pda::g_fps_fail_total), &z, sizeof(z)) != hipSuccess) {
+            pda::set_error("pda_fps_coop_timeouts: reset failed: %s", hipGetErrorString(hipGetLastError()));
+            return PDA_ERR_LAUNCH;
+        }
+    }
+    return PDA_OK;
+}
+
+PDA_API int pda_debug_fps_spin_limit(int polls) {
+    const int v = polls < 0 ? pda::FPS_SPIN_LIMIT : polls;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpyToSymbol(HIP_SYMBOL(pda::g_fps_spin_limit), &v, sizeof(v)) != hipSuccess) {
+        pda::set_error("pda_debug_fps_spin_limit: %s", hipGetErrorString(hipGetLastError()));
+        return PDA_ERR_LAUNCH;
+    }
+    return PDA_OK;
+}
 
 PDA_API int pda_opt_n_threads(int work_size) {
     // cuda_utils.h:10-14: pow_2 = log(double(n)) / log(2.0) truncated; clamp(1 << pow_2, 1, 1024).

@@ -70,6 +70,18 @@ def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz
     return 1
 
 
+def fps_coop_timeouts(reset=False):
+    """Exchanges of the multi-workgroup FPS form (n > 24576) that timed out and were recovered on the device since
+    the library was loaded / last reset (include/pda_pointnet2.h).  Synchronises the device."""
+    total = ctypes.c_ulonglong(0)
+    _lib.check(_lib.load().pda_fps_coop_timeouts(ctypes.byref(total), 1 if reset else 0), "pda_fps_coop_timeouts")
+    return int(total.value)
+
+
+def debug_fps_spin_limit(polls):
+    _lib.check(_lib.load().pda_debug_fps_spin_limit(int(polls)), "pda_debug_fps_spin_limit")
+
+
 def ellipsoid_query(new_xyz, xyz, e1, e2, e3, nsample):
     """pointnet2_api.cpp:16 / ellipsoid_query.cpp:13: allocates and returns idx (b, m, nsample) in the reference.  Not
     on the PDA-SSD path and not implemented: pda_ellipsoid_query returns PDA_ERR_UNSUPPORTED and this raises PdaError."""

@@ -1,0 +1,39 @@
+"""-m gpu: the multi-workgroup FPS form (24576 < n <= 65536, csrc/fps.hip fps_pruned_kernel<16, true>) can no longer
+fail silently: a timed-out winner exchange is counted, reported through the C ABI
+(pda_fps_coop_timeouts) and the scene is recomputed on the device, so indices and `temp` stay the exact result."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+from test_hip_parity import cloud, ext, fps_both  # noqa: E402,F401
+
+
+@pytest.mark.parametrize("b,n,m", [(2, 30000, 200), (1, 50000, 150)])    # K = 2 and K = 4 workgroups per scene
+def test_cooperative_fps_reports_no_timeouts_when_healthy(ext, oracle, b, n, m):
+    ext.fps_coop_timeouts(reset=True)
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, cloud(b, n, seed=n), m)
+    assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    assert ext.fps_coop_timeouts() == 0
+
+
+def test_forced_exchange_timeout_is_counted_and_recovered(ext, oracle):
+    """Poll budget 0: a workgroup gives up at the first exchange whose partner records are not there yet.  The status
+    reaches the host (non-zero count) and the follow-up kernel recomputes the scene: still bit-exact."""
+    b, n, m = 3, 30000, 120
+    xyz = cloud(b, n, seed=77)
+    ext.fps_coop_timeouts(reset=True)
+    ext.debug_fps_spin_limit(0)
+    try:
+        idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+        failures = ext.fps_coop_timeouts(reset=True)
+    finally:
+        ext.debug_fps_spin_limit(-1)
+    assert failures > 0, "the forced timeout was not reported"
+    assert (idx_d >= 0).all() and (idx_d < n).all()          # nothing unwritten / out of range reaches a gather
+    assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    # and the next healthy launch is clean again
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+    assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    assert ext.fps_coop_timeouts() == 0
