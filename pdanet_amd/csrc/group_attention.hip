@@ -32,13 +32,11 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 
 template <int HD>
 struct GaPtrs {
-    // element (b, s, which, head, d) of qkv (Bn, S, 3, H, HD)
-    __device__ __forceinline__ static size_t qkv(int S, int H, size_t b, int s, int which, int head) {
-        return (((b * S + s) * 3 + which) * H + head) * (size_t)HD;
+    // element (row, which, head, d) of qkv (rows, 3, H, HD); row = b * S + s in the dense layout
+    __device__ __forceinline__ static size_t qkv(int H, size_t row, int which, int head) {
+        return ((row * 3 + which) * H + head) * (size_t)HD;
     }
-    __device__ __forceinline__ static size_t o(int S, int H, size_t b, int s, int head) {
-        return ((b * S + s) * H + head) * (size_t)HD;
-    }
+    __device__ __forceinline__ static size_t o(int H, size_t row, int head) { return (row * H + head) * (size_t)HD; }
 };
 
 // A 32-token x HD tile moves between HBM and the MFMA operand layout through a wave-private LDS
@@ -95,10 +93,15 @@ struct Tile {
 };
 
 // S: tokens per group (8, 16 or 32).  A wave covers G = 32/S groups of one head.
-template <int S, int HD, bool BWD, typename TIO>
+// RAGGED (csrc/ragged.hip): the rows are COMPACT -- group b owns rows [off[b], off[b] + cnt[b]), cnt[b] <= S distinct
+// tokens; slots >= cnt[b] are the repeats of token 0 the dense layout would hold.  They are not computed: their keys
+// are masked and key 0 enters the softmax with weight S - cnt + 1 (score + log of it), which is exactly the sum over
+// the repeated keys; their queries (identical to query 0) are not evaluated.  The tile logic is unchanged.
+template <int S, int HD, bool BWD, typename TIO, bool RAGGED>
 __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __restrict__ qkv, const TIO* __restrict__ dout,
                                                                TIO* __restrict__ out, float* __restrict__ lse,
-                                                               TIO* __restrict__ dqkv, int64_t nb, int H, float scale) {
+                                                               TIO* __restrict__ dqkv, int64_t nb, int H, float scale,
+                                                               const int32_t* __restrict__ cnt, const int32_t* __restrict__ off) {
     constexpr int G = 32 / S;
     using TL = Tile<HD>;
     constexpr int TRN = 2 * 32 * 33;  // P and dS transposes (backward), stride 33
@@ -111,25 +114,50 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
     const int head = (int)(task % H);
     const int64_t b0 = (task / H) * G;                      // first group of this wave
     if (b0 >= nb) return;
+    // RAGGED: tokens and first compact row of the wave's G groups (wave-uniform); a group past the end has 0 tokens
+    int gn[G];
+    int64_t go[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const bool gv = b0 + g < nb;
+        gn[g] = RAGGED ? (gv ? cnt[b0 + g] : 0) : (gv ? S : 0);
+        go[g] = RAGGED ? off[gv ? b0 + g : b0] : (b0 + g) * S;
+    }
+    auto g_n = [&](int g) -> int { int v = gn[0];
+#pragma unroll
+        for (int q = 1; q < G; ++q) v = g == q ? gn[q] : v;
+        return v; };
+    auto g_o = [&](int g) -> int64_t { int64_t v = go[0];
+#pragma unroll
+        for (int q = 1; q < G; ++q) v = g == q ? go[q] : v;
+        return v; };
+    // tile row r = (group r / S, slot r % S) -> its row in HBM; invalid rows read group b0's token 0 and are zeroed
+    auto tile_row = [&](int r, bool& valid) -> int64_t {
+        const int g = r / S, sl_ = r % S;
+        valid = sl_ < g_n(g);
+        return valid ? g_o(g) + sl_ : go[0];
+    };
     // my column / row as operand lane: group g = c / S, token s = c % S
     const int64_t bl = b0 + c / S;
     const int sl = c % S;
-    const bool ok = bl < nb;
+    const bool ok = bl < nb && sl < g_n(c / S);
     // row r of the wave's 32-token tile
     // Loads never branch on validity (a divergent branch around a load serialises load -> wait ->
     // MFMA): rows of groups past the end read group b0's row instead and are zeroed by a select.
     auto in_row = [&](int which) {
-        return [=](int r, bool& valid) -> const TIO* {
-            const int64_t b = b0 + r / S;
-            valid = b < nb;
-            return qkv + GaPtrs<HD>::qkv(S, H, valid ? b : b0, r % S, which, head);
+        return [&, which](int r, bool& valid) -> const TIO* {
+            return qkv + GaPtrs<HD>::qkv(H, (size_t)tile_row(r, valid), which, head);
         };
     };
-    auto do_row = [=](int r, bool& valid) -> const TIO* {
-        const int64_t b = b0 + r / S;
-        valid = b < nb;
-        return dout + GaPtrs<HD>::o(S, H, valid ? b : b0, r % S, head);
+    auto do_row = [&](int r, bool& valid) -> const TIO* {
+        return dout + GaPtrs<HD>::o(H, (size_t)tile_row(r, valid), head);
     };
+    // key j of the tile as seen by my query column: inside my group and a real (distinct) token?  bias = log of the
+    // multiplicity of key 0 (RAGGED); a group past the end keeps key 0 so that its (unused) column stays finite
+    auto key_ok = [&](int j) -> bool {
+        return (j / S) == (c / S) && (j % S) < max(g_n(j / S), 1);
+    };
+    const float lnw = RAGGED ? __logf((float)(S - max(g_n(c / S), 1) + 1)) : 0.f;
 
     float kq[HD / 2], qq[HD / 2];
     {
@@ -152,8 +180,8 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
         float m = -__builtin_inff();
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool same = (acc_row(r, h2) / S) == (c / S);
-            T[r] = same ? T[r] * scale : -__builtin_inff();
+            const int j = acc_row(r, h2);
+            T[r] = key_ok(j) ? T[r] * scale + ((RAGGED && (j % S) == 0) ? lnw : 0.f) : -__builtin_inff();
             m = fmaxf(m, T[r]);
         }
         m = fmaxf(m, __shfl_xor(m, 32));
@@ -170,17 +198,16 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
         lse_i = ok ? lse[(bl * H + head) * S + sl] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const bool same = (acc_row(r, h2) / S) == (c / S);
-            P[r] = same ? __expf(T[r] * scale - lse_i) : 0.f;
+            const int j = acc_row(r, h2);
+            P[r] = key_ok(j) ? __expf(T[r] * scale + ((RAGGED && (j % S) == 0) ? lnw : 0.f) - lse_i) : 0.f;
         }
     }
 
     // A operand fetched in accumulator key order: x[key j(t,h2)][dblk*32 + c] (128-byte rows per half wave)
     auto key_val = [&](int which, int t, int col) -> float {
-        const int j = acc_row(t, h2);
-        const int64_t bj = b0 + j / S;
-        const bool valid = bj < nb;
-        const float v = load1(qkv + GaPtrs<HD>::qkv(S, H, valid ? bj : b0, j % S, which, head) + col);
+        bool valid;
+        const int64_t row = tile_row(acc_row(t, h2), valid);
+        const float v = load1(qkv + GaPtrs<HD>::qkv(H, (size_t)row, which, head) + col);
         return valid ? v : 0.f;
     };
 
@@ -197,9 +224,10 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             }
             TL::from_acc(lds, O, dblk, lane);
         }
-        TL::store(lds, [=](int r) -> TIO* {
-            const int64_t b = b0 + r / S;
-            return (b < nb) ? out + GaPtrs<HD>::o(S, H, b, r % S, head) : nullptr;
+        TL::store(lds, [&](int r) -> TIO* {
+            bool valid;
+            const int64_t row = tile_row(r, valid);
+            return valid ? out + GaPtrs<HD>::o(H, (size_t)row, head) : nullptr;
         }, lane);
         return;
     } else {
@@ -240,16 +268,16 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             dSn[t] = ts[c * 33 + acc_row(t, h2)];
         }
         auto qry_o_val = [&](int t, int col) -> float {  // dO[query i(t,h2)][col]
-            const int i = acc_row(t, h2);
-            const int64_t bi = b0 + i / S;
-            const bool valid = bi < nb;
-            const float v = load1(dout + GaPtrs<HD>::o(S, H, valid ? bi : b0, i % S, head) + col);
+            bool valid;
+            const int64_t row = tile_row(acc_row(t, h2), valid);
+            const float v = load1(dout + GaPtrs<HD>::o(H, (size_t)row, head) + col);
             return valid ? v : 0.f;
         };
         auto out_row = [&](int which) {
-            return [=](int r) -> TIO* {
-                const int64_t b = b0 + r / S;
-                return (b < nb) ? dqkv + GaPtrs<HD>::qkv(S, H, b, r % S, which, head) : nullptr;
+            return [&, which](int r) -> TIO* {
+                bool valid;
+                const int64_t row = tile_row(r, valid);
+                return valid ? dqkv + GaPtrs<HD>::qkv(H, (size_t)row, which, head) : nullptr;
             };
         };
         // dQ^T = K^T dS^T
@@ -294,16 +322,18 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
     }
 }
 
-template <bool BWD, typename TIO>
+template <bool BWD, typename TIO, bool RAGGED = false>
 static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, float* lse, TIO* dqkv,
-                                  int64_t nb, int s, int h, int hd, hipStream_t stream, const char* what) {
+                                  int64_t nb, int s, int h, int hd, hipStream_t stream, const char* what,
+                                  const int32_t* cnt = nullptr, const int32_t* off = nullptr) {
     PDA_REQUIRE(nb >= 0 && h >= 1, "%s: bad size", what);
     if (nb == 0) return PDA_OK;
     PDA_REQUIRE(qkv && lse && (BWD ? (dout && dqkv) : (out != nullptr)), "%s: null pointer", what);
+    PDA_REQUIRE(!RAGGED || (cnt && off), "%s: null pointer", what);
     const int G = 32 / (s > 0 ? s : 1);
     const float scale = 1.0f / sqrtf((float)hd);
-    void (*kern)(const TIO*, const TIO*, TIO*, float*, TIO*, int64_t, int, float) = nullptr;
-#define PDA_GA_CASE(SS, DD) if (s == SS && hd == DD) kern = group_attention_kernel<SS, DD, BWD, TIO>
+    void (*kern)(const TIO*, const TIO*, TIO*, float*, TIO*, int64_t, int, float, const int32_t*, const int32_t*) = nullptr;
+#define PDA_GA_CASE(SS, DD) if (s == SS && hd == DD) kern = group_attention_kernel<SS, DD, BWD, TIO, RAGGED>
     PDA_GA_CASE(32, 64); PDA_GA_CASE(16, 64); PDA_GA_CASE(8, 64);
     PDA_GA_CASE(32, 128); PDA_GA_CASE(16, 128); PDA_GA_CASE(8, 128);
     PDA_GA_CASE(32, 32); PDA_GA_CASE(16, 32); PDA_GA_CASE(8, 32);
@@ -315,7 +345,7 @@ static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, flo
     const int64_t tasks = divup64(nb, G) * h;
     const int64_t blocks = divup64(tasks, 4);
     PDA_REQUIRE(blocks < INT32_MAX, "%s: too many groups", what);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, qkv, dout, out, lse, dqkv, nb, h, scale);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, qkv, dout, out, lse, dqkv, nb, h, scale, cnt, off);
     return check_launch(what);
 }
 
@@ -343,4 +373,18 @@ PDA_API int pda_group_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* gr
                                          int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream) {
     return pda::launch_group_attention<true, pda::bf16_t>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups,
                                                           seq, heads, head_dim, (hipStream_t)stream, "pda_group_attention_bwd_bf16");
+}
+
+// Compact ("ragged") rows: qkv (U, 3, H, hd), out / grad (U, H * hd), lse (groups, H, seq); see csrc/ragged.hip.
+PDA_API int pda_group_attention_ragged_fwd(const float* qkv, const int32_t* cnt, const int32_t* off, float* out, float* lse,
+                                           int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream) {
+    return pda::launch_group_attention<false, float, true>(qkv, nullptr, out, lse, nullptr, num_groups, seq, heads, head_dim,
+                                                           (hipStream_t)stream, "pda_group_attention_ragged_fwd", cnt, off);
+}
+
+PDA_API int pda_group_attention_ragged_bwd(const float* qkv, const float* grad_out, const float* lse, const int32_t* cnt,
+                                           const int32_t* off, float* grad_qkv, int64_t num_groups, int seq, int heads,
+                                           int head_dim, pda_stream_t stream) {
+    return pda::launch_group_attention<true, float, true>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups, seq,
+                                                          heads, head_dim, (hipStream_t)stream, "pda_group_attention_ragged_bwd", cnt, off);
 }

@@ -449,3 +449,65 @@ def assemble_tokens_grad(grad_out, dscale, feats, idx, grad_rppe, grad_dscale, g
           _chk(idx, "idx", I32), _chk(grad_rppe, "grad_rppe", F32), _chk(grad_dscale, "grad_dscale", F32),
           _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c)
     return 1
+
+
+# ---- unique-token ("ragged") execution of a PDA scale (include/pda_train.h, csrc/ragged.hip) --------------------
+def ragged_plan(idx, cnt, off, rowmap, groups, nsample):
+    """idx (groups, nsample) -> cnt (groups), off (groups + 1), rowmap (groups * nsample capacity).  No synchronisation."""
+    _numel_ok(idx, groups * nsample, "idx"); _numel_ok(cnt, groups, "cnt"); _numel_ok(off, groups + 1, "off")
+    _numel_ok(rowmap, groups * nsample, "rowmap")
+    _call("pda_ragged_plan", idx, _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(rowmap, "rowmap", I32),
+          groups, nsample)
+    return 1
+
+
+def assemble_tokens_ragged(rppe, dscale, feats, idx, glob, rowmap, off, out, tokens, b, n, m, nsample, c):
+    t = b * m * nsample
+    _numel_ok(rppe, t * c, "rppe"); _numel_ok(dscale, t, "dscale"); _numel_ok(feats, b * n * c, "feats"); _numel_ok(idx, t, "idx")
+    _numel_ok(glob, b * m * c, "glob"); _numel_ok(out, tokens * 4 * c, "out"); _numel_ok(rowmap, tokens, "rowmap"); _numel_ok(off, b * m + 1, "off")
+    _call("pda_assemble_tokens_ragged", rppe, _chk(rppe, "rppe", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
+          _chk(idx, "idx", I32), _chk(glob, "glob", F32), _chk(rowmap, "rowmap", I32), _chk(off, "off", I32), _chk(out, "out", F32),
+          tokens, b, n, m, nsample, c)
+    return 1
+
+
+def assemble_tokens_ragged_grad(grad_out, dscale, feats, idx, cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, tokens, b, n, m, nsample, c):
+    t = b * m * nsample
+    _numel_ok(grad_out, tokens * 4 * c, "grad_out"); _numel_ok(grad_rppe, t * c, "grad_rppe"); _numel_ok(grad_dscale, t, "grad_dscale")
+    _numel_ok(grad_feats, b * n * c, "grad_feats"); _numel_ok(grad_glob, b * m * c, "grad_glob"); _numel_ok(cnt, b * m, "cnt"); _numel_ok(off, b * m + 1, "off")
+    _call("pda_assemble_tokens_ragged_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
+          _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_rppe, "grad_rppe", F32),
+          _chk(grad_dscale, "grad_dscale", F32), _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c)
+    return 1
+
+
+def add_max_pool_ragged(a, b, cnt, off, out, arg, tokens, groups, d):
+    _numel_ok(a, tokens * d, "a"); _numel_ok(b, tokens * d, "b"); _numel_ok(out, groups * d, "out"); _numel_ok(arg, groups * d, "arg")
+    _numel_ok(cnt, groups, "cnt"); _numel_ok(off, groups + 1, "off")
+    _call("pda_add_max_pool_ragged", a, _chk(a, "a", F32), _chk(b, "b", F32), _chk(cnt, "cnt", I32), _chk(off, "off", I32),
+          _chk(out, "out", F32), _chk(arg, "arg", torch.uint8), groups, d)
+    return 1
+
+
+def max_pool_scatter_ragged(grad_out, arg, rowmap, off, grad_x, tokens, groups, nsample, d):
+    _numel_ok(grad_out, groups * d, "grad_out"); _numel_ok(arg, groups * d, "arg"); _numel_ok(grad_x, tokens * d, "grad_x")
+    _numel_ok(rowmap, tokens, "rowmap"); _numel_ok(off, groups + 1, "off")
+    _call("pda_max_pool_scatter_ragged", grad_out, _chk(grad_out, "grad_out", F32), _chk(arg, "arg", torch.uint8),
+          _chk(rowmap, "rowmap", I32), _chk(off, "off", I32), _chk(grad_x, "grad_x", F32), tokens, groups, nsample, d)
+    return 1
+
+
+def group_attention_ragged_fwd(qkv, cnt, off, out, lse, tokens, num_groups, seq, heads, head_dim):
+    _numel_ok(qkv, tokens * 3 * heads * head_dim, "qkv"); _numel_ok(out, tokens * heads * head_dim, "out")
+    _numel_ok(lse, num_groups * heads * seq, "lse"); _numel_ok(cnt, num_groups, "cnt"); _numel_ok(off, num_groups + 1, "off")
+    _call("pda_group_attention_ragged_fwd", qkv, _chk(qkv, "qkv", F32), _chk(cnt, "cnt", I32), _chk(off, "off", I32),
+          _chk(out, "out", F32), _chk(lse, "lse", F32), num_groups, seq, heads, head_dim)
+    return 1
+
+
+def group_attention_ragged_bwd(qkv, grad_out, lse, cnt, off, grad_qkv, tokens, num_groups, seq, heads, head_dim):
+    _numel_ok(qkv, tokens * 3 * heads * head_dim, "qkv"); _numel_ok(grad_qkv, tokens * 3 * heads * head_dim, "grad_qkv")
+    _numel_ok(grad_out, tokens * heads * head_dim, "grad_out"); _numel_ok(lse, num_groups * heads * seq, "lse")
+    _call("pda_group_attention_ragged_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32), _chk(lse, "lse", F32),
+          _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
+    return 1

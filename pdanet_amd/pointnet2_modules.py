@@ -604,6 +604,14 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         channel-major branch below / the reference (:854-945)."""
         B, npoint = new_xyz.shape[0], new_xyz.shape[1]
         idxs = self._ball_queries(xyz, new_xyz)
+        # distinct-token plans of all scales (ONE host synchronisation per layer); None: run this scale dense
+        plans = [None] * len(idxs)
+        C0 = features.shape[1]
+        if pointnet2_utils.RaggedTransformerBlock.supported(4 * C0, self.Local_pointformer[0].self_attn.num_heads,
+                                                            max(self.nsamples), features) \
+                and all(ns in pointnet2_utils.GroupAttention.SUPPORTED_SEQ for ns in self.nsamples) \
+                and FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL:
+            plans = [p if p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in pointnet2_utils.ragged_plans(idxs)]
         feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
         global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)
         centre = new_xyz.unsqueeze(2)                                         # (B, M, 1, 3)
@@ -640,6 +648,12 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                         dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
+            if plans[i] is not None and pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
+                # the encoder on the distinct tokens only (csrc/ragged.hip): x (U, 4C) -> (B, M, 4C)
+                x = pointnet2_utils.AssembleTokensRagged.apply(rppe, dscale, feats_pm, idxs[i], glob, plans[i])
+                x = pointnet2_utils.ragged_transformer_block(self.Local_pointformer[i], x, plans[i]).view(B, npoint, -1)
+                outs.append(_mlp_lastdim(self.fin_conv[i], x))
+                continue
             if pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
                 x = pointnet2_utils.AssembleTokens.apply(rppe, dscale, feats_pm, idxs[i], glob)   # (B, M, ns, 4C)
             else:

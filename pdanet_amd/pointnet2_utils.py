@@ -782,6 +782,151 @@ def transformer_block(tr, x, pool=False):
                                   tr.linear2.weight, tr.linear2.bias, at.num_heads, tr.norm1.eps, tr.norm2.eps, pool)
 
 
+# ---- unique-token ("ragged") execution of a PDA scale (csrc/ragged.hip) --------------------------------------------
+# RAGGED_TOKENS: run the encoder of a PDA scale on the distinct (centre, neighbour) tokens only.  RAGGED_MAX_FRACTION:
+# use it when the distinct tokens are at most this share of B*M*nsample (above it the bookkeeping costs more than it saves).
+RAGGED_TOKENS = True
+RAGGED_MAX_FRACTION = 0.85
+
+
+class RaggedPlan:
+    """cnt (G) / off (G+1) / rowmap (U) of one scale (device tensors) and U, the number of distinct tokens (host int)."""
+    __slots__ = ("cnt", "off", "rowmap", "tokens", "groups", "nsample")
+
+    def __init__(self, cnt, off, rowmap, tokens, groups, nsample):
+        self.cnt, self.off, self.rowmap, self.tokens, self.groups, self.nsample = cnt, off, rowmap, tokens, groups, nsample
+
+    @property
+    def fraction(self):
+        return self.tokens / float(self.groups * self.nsample)
+
+
+def ragged_plans(idxs):
+    """One RaggedPlan per neighbour-index tensor (B, M, ns) of a layer.  ONE host synchronisation for all of them: the
+    token counts size the GEMMs of the encoder (the reference's backbone synchronises once per forward as well,
+    IASSD_backbone.py:134-137)."""
+    parts = []
+    for idx in idxs:
+        G, ns = idx.shape[0] * idx.shape[1], idx.shape[2]
+        cnt = torch.empty((G,), dtype=torch.int32, device=idx.device)
+        off = torch.empty((G + 1,), dtype=torch.int32, device=idx.device)
+        rowmap = torch.empty((G * ns,), dtype=torch.int32, device=idx.device)
+        pointnet2.ragged_plan(idx, cnt, off, rowmap, G, ns)
+        parts.append((cnt, off, rowmap, G, ns))
+    totals = torch.stack([p[1][-1] for p in parts]).tolist()
+    return [RaggedPlan(c, o, r[:u], int(u), G, ns) for (c, o, r, G, ns), u in zip(parts, totals)]
+
+
+class AssembleTokensRagged(Function):
+    """AssembleTokens writing only the distinct tokens: x (U, 4C).  The gradients of rppe / dscale come back dense
+    (B,M,ns,.) with zeros at the repeat slots -- the position MLP and DensityNet in front of this still run dense."""
+
+    @staticmethod
+    def forward(ctx, rppe, dscale, feats_pm, idx, glob, plan):
+        B, M, ns, C = rppe.shape
+        N = feats_pm.shape[1]
+        rppe, dscale, feats_pm, glob = rppe.contiguous(), dscale.contiguous(), feats_pm.contiguous(), glob.contiguous()
+        out = torch.empty((plan.tokens, 4 * C), dtype=torch.float32, device=rppe.device)
+        pointnet2.assemble_tokens_ragged(rppe, dscale, feats_pm, idx, glob, plan.rowmap, plan.off, out, plan.tokens, B, N, M, ns, C)
+        ctx.save_for_backward(dscale, feats_pm, idx, plan.cnt, plan.off)
+        ctx.dims = (B, N, M, ns, C, plan.tokens)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        dscale, feats_pm, idx, cnt, off = ctx.saved_tensors
+        B, N, M, ns, C, U = ctx.dims
+        dev = grad_out.device
+        g_rppe = torch.empty((B, M, ns, C), dtype=torch.float32, device=dev)
+        g_ds = torch.empty_like(dscale)
+        g_feats = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
+        g_glob = torch.empty((B, M, C), dtype=torch.float32, device=dev)
+        pointnet2.assemble_tokens_ragged_grad(grad_out.contiguous(), dscale, feats_pm, idx, cnt, off, g_rppe, g_ds, g_feats, g_glob,
+                                              U, B, N, M, ns, C)
+        return g_rppe, g_ds, g_feats, None, g_glob, None
+
+
+class RaggedTransformerBlock(Function):
+    """TransformerBlock (pool=True) on the compact token matrix x (U, D) of a scale: the same operator sequence on U
+    instead of groups * nsample rows, attention and the max-pool tail on the ragged groups (fp32 path)."""
+
+    @staticmethod
+    def supported(d, heads, nsample, x):
+        return (RAGGED_TOKENS and x.is_cuda and x.dtype == torch.float32 and d in (256, 512, 1024) and d % heads == 0
+                and nsample in GroupAttention.SUPPORTED_SEQ and d // heads in GroupAttention.SUPPORTED_HD
+                and not torch.is_autocast_enabled() and not DENSE_BF16)
+
+    @staticmethod
+    def forward(ctx, x, plan, n1w, n1b, in_w, in_b, out_w, out_b, n2w, n2b, w1, b1, w2, b2, heads, eps1, eps2):
+        x = x.contiguous()
+        U, D = x.shape
+        G, S, hd = plan.groups, plan.nsample, D // heads
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        src1, ssum, src2 = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+        st1, st2 = torch.empty((U, 2), **f32), torch.empty((U, 2), **f32)
+        lse = torch.empty((G, heads, S), **f32)
+        pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, U, D, eps1)
+        qkv = torch.nn.functional.linear(src1, in_w, in_b)
+        a = torch.empty((U, D), **f32)
+        pointnet2.group_attention_ragged_fwd(qkv, plan.cnt, plan.off, a, lse, U, G, S, heads, hd)
+        proj = torch.nn.functional.linear(a, out_w, out_b)
+        pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, U, D, eps2)
+        del proj
+        h = torch._addmm_activation(b1, src2, w1.t())          # relu(src2 W1^T + b1), ReLU in the GEMM epilogue
+        ffn = torch.nn.functional.linear(h, w2, b2)
+        y = torch.empty((G, D), **f32)
+        arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
+        pointnet2.add_max_pool_ragged(src2, ffn, plan.cnt, plan.off, y, arg, U, G, D)
+        ctx.save_for_backward(x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg,
+                              plan.cnt, plan.off, plan.rowmap)
+        ctx.heads, ctx.dims = heads, (G, S)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, st1, src1, qkv, lse, a, ssum, st2, src2, h, n1w, in_w, out_w, n2w, w1, w2, arg, cnt, off, rowmap = ctx.saved_tensors
+        U, D = x.shape
+        G, S = ctx.dims
+        heads = ctx.heads
+        hd = D // heads
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        dy2 = torch.empty((U, D), **f32)
+        pointnet2.max_pool_scatter_ragged(dy.contiguous(), arg, rowmap, off, dy2, U, G, S, D)
+        d_h = dy2.mm(w2)
+        gw2, gb2 = _wgrad(h, dy2, w2, True, False)
+        d_h = torch.ops.aten.threshold_backward(d_h, h, 0)
+        gw1, gb1 = _wgrad(src2, d_h, w1, True, False)
+        d_lin1 = d_h.mm(w1)
+        del d_h
+        d_s = torch.empty((U, D), **f32)
+        gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
+        scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
+        pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, U, D, grad_y2=d_lin1)
+        del d_lin1
+        d_a = d_s.mm(out_w)
+        gwo, gbo = _wgrad(a, d_s, out_w, True, False)
+        dqkv = torch.empty_like(qkv)
+        pointnet2.group_attention_ragged_bwd(qkv, d_a, lse, cnt, off, dqkv, U, G, S, heads, hd)
+        del d_a
+        gwi, gbi = _wgrad(src1, dqkv, in_w, True, False)
+        d_src1 = _mm_nn(dqkv, in_w, False, acc=d_s)        # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
+        del dqkv
+        d_x = torch.empty_like(x)
+        gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)
+        pointnet2.layer_norm_bwd(x, d_src1, n1w, st1, d_x, gn1w, gn1b, scratch, U, D)
+        return d_x, None, gn1w, gn1b, gwi, gbi, gwo, gbo, gn2w, gn2b, gw1, gb1, gw2, gb2, None, None, None
+
+
+def ragged_transformer_block(tr, x, plan):
+    at = tr.self_attn
+    return RaggedTransformerBlock.apply(x, plan, tr.norm1.weight, tr.norm1.bias, at.in_proj_weight, at.in_proj_bias,
+                                        at.out_proj.weight, at.out_proj.bias, tr.norm2.weight, tr.norm2.bias,
+                                        tr.linear1.weight, tr.linear1.bias, tr.linear2.weight, tr.linear2.bias,
+                                        at.num_heads, tr.norm1.eps, tr.norm2.eps)
+
+
 class LayerNormResidual(Function):
     """MI355X extension: y = LayerNorm(x [+ residual]) over the last dim (csrc/layer_norm.hip); one forward
     kernel, one single-pass backward kernel (+ a tiny fixed-order reduction of the gamma/beta partials)."""
