@@ -610,7 +610,8 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         if pointnet2_utils.RaggedTransformerBlock.supported(4 * C0, self.Local_pointformer[0].self_attn.num_heads,
                                                             max(self.nsamples), features) \
                 and all(ns in pointnet2_utils.GroupAttention.SUPPORTED_SEQ for ns in self.nsamples) \
-                and FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL:
+                and FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL \
+                and not torch.cuda.is_current_stream_capturing():    # the plan's token count is read on the host
             plans = [p if p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in pointnet2_utils.ragged_plans(idxs)]
         feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
         global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)

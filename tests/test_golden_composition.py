@@ -235,15 +235,26 @@ def test_inference_forward_captures_into_hipgraph():
     """The whole backbone inference forward (side-stream D-FPS prefetch, fused SA kernels, point-
     major PDA layers) is capturable: no allocation/synchronisation/host copies in the C ABI or the
     model code.  Replay must reproduce the eager result bit for bit."""
-    from pdanet_amd import synth, fused_ops
+    from pdanet_amd import synth, fused_ops, pointnet2_utils as pu
     from pdanet_amd.backbone import build_backbone
     model, _ = build_backbone("once_pda_ssd.yaml")
     model = fill_deterministic(model).cuda().eval()
     fused_ops.enable_fused(model)
     pts = torch.from_numpy(synth.batch_points(2, 4096, config_id=8)).cuda()
     with torch.no_grad():
-        for _ in range(2):
-            ref = model({"batch_size": 2, "points": pts})["centers_features"].clone()
+        ragged = model({"batch_size": 2, "points": pts})["centers_features"].clone()
+        # under capture the PDA encoder runs in its dense form (the unique-token form reads a token count on the
+        # host, pointnet2_utils.ragged_plans): the bit-for-bit reference is the eager dense form
+        pu.RAGGED_TOKENS = False
+        try:
+            for _ in range(2):
+                ref = model({"batch_size": 2, "points": pts})["centers_features"].clone()
+        finally:
+            pu.RAGGED_TOKENS = True
+    # same result up to fp32 re-association -- except where a 1e-6 score difference flips the top-k centre choice of
+    # layers 2-3 (random-init scores are nearly equal), which replaces whole rows: compare the bulk
+    agree = ((ragged - ref).abs() <= 2e-4 * max(1.0, ref.abs().max().item())).float().mean().item()
+    assert agree > 0.97, agree
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.no_grad(), torch.cuda.graph(g):
