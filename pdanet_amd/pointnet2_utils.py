@@ -846,6 +846,21 @@ class AssembleTokensRagged(Function):
         return g_rppe, g_ds, g_feats, None, g_glob, None
 
 
+def _wgrad_ragged(x2d, g2d, weight, want_bias):
+    """Weight / bias gradient at the token counts of the ragged path.  They change from step to step, so no library
+    selection was tuned for them, and the default heuristic runs these K = tokens reductions at 20-70 TFLOP/s where
+    csrc/wgrad.hip reaches 60-115 (profiles/r02_gemm_probe.txt); below ~8k tokens the library is ahead."""
+    n_out, n_in = weight.shape
+    tokens = x2d.shape[0]
+    if (LINEAR_WGRAD_KERNEL and tokens >= 8192 and min(n_out, n_in) >= 128 and n_out % 4 == 0 and n_in % 4 == 0
+            and x2d.dtype == torch.float32 and g2d.dtype == torch.float32):
+        gw = torch.empty_like(weight)
+        gb = torch.empty((n_out,), dtype=torch.float32, device=x2d.device) if want_bias else None
+        pointnet2.linear_wgrad(x2d.contiguous(), g2d.contiguous(), gw, gb, tokens, n_in, n_out)
+        return gw, gb
+    return g2d.t().mm(x2d), (g2d.sum(0) if want_bias else None)
+
+
 class RaggedTransformerBlock(Function):
     """TransformerBlock (pool=True) on the compact token matrix x (U, D) of a scale: the same operator sequence on U
     instead of groups * nsample rows, attention and the max-pool tail on the ragged groups (fp32 path)."""
@@ -895,9 +910,9 @@ class RaggedTransformerBlock(Function):
         dy2 = torch.empty((U, D), **f32)
         pointnet2.max_pool_scatter_ragged(dy.contiguous(), arg, rowmap, off, dy2, U, G, S, D)
         d_h = dy2.mm(w2)
-        gw2, gb2 = _wgrad(h, dy2, w2, True, False)
+        gw2, gb2 = _wgrad_ragged(h, dy2, w2, True)
         d_h = torch.ops.aten.threshold_backward(d_h, h, 0)
-        gw1, gb1 = _wgrad(src2, d_h, w1, True, False)
+        gw1, gb1 = _wgrad_ragged(src2, d_h, w1, True)
         d_lin1 = d_h.mm(w1)
         del d_h
         d_s = torch.empty((U, D), **f32)
@@ -906,11 +921,11 @@ class RaggedTransformerBlock(Function):
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, U, D, grad_y2=d_lin1)
         del d_lin1
         d_a = d_s.mm(out_w)
-        gwo, gbo = _wgrad(a, d_s, out_w, True, False)
+        gwo, gbo = _wgrad_ragged(a, d_s, out_w, True)
         dqkv = torch.empty_like(qkv)
         pointnet2.group_attention_ragged_bwd(qkv, d_a, lse, cnt, off, dqkv, U, G, S, heads, hd)
         del d_a
-        gwi, gbi = _wgrad(src1, dqkv, in_w, True, False)
+        gwi, gbi = _wgrad_ragged(src1, dqkv, in_w, True)
         d_src1 = _mm_nn(dqkv, in_w, False, acc=d_s)        # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv
         d_x = torch.empty_like(x)
