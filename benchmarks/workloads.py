@@ -106,7 +106,9 @@ class KernelTimers:
         ext.farthest_point_sampling_wrapper = timed(unwrap(ext.farthest_point_sampling_wrapper), self.fps_events,
                                                     lambda b, n, m, *r: (b, n, m))
         ext.ball_query_multi = timed(unwrap(ext.ball_query_multi), self.bq_events,
-                                     lambda b, n, m, radii, ns, *r: (b, n, m, tuple(radii), tuple(ns)))
+                                     lambda b, n, m, radii, ns, *r: (b, n, m, tuple(radii), tuple(ns), "scalar-stream brute force"))
+        ext.ball_query_cells = timed(unwrap(ext.ball_query_cells), self.bq_events,
+                                     lambda b, n, m, radii, ns, *r: (b, n, m, tuple(radii), tuple(ns), "cell list"))
         ext.linear_wgrad = timed(unwrap(ext.linear_wgrad), self.wgrad_events,
                                  lambda x, g, gw, gb, tokens, n_in, n_out: (tokens, n_in, n_out))
 
@@ -140,21 +142,22 @@ class KernelTimers:
         """The layer-0 ball-query launch (largest M*N of the step; both radii in one pass)."""
         if not self.bq_events:
             return None
-        b, n, m, radii, nss = max((e[2:] for e in self.bq_events), key=lambda s: s[1] * s[2])
-        t = self._mean_s([e[:2] for e in self.bq_events if e[2:] == (b, n, m, radii, nss)])
+        b, n, m, radii, nss, path = max((e[2:] for e in self.bq_events), key=lambda s: s[1] * s[2])
+        t = self._mean_s([e[:2] for e in self.bq_events if e[2:] == (b, n, m, radii, nss, path)])
         alg = ball_query_algorithmic_bytes(n, m, nss) * b
         ach = alg / t / 1e9
         tests = float(b) * n * m * len(radii)
         peak_tests = VALU_LANE_OPS / BALL_QUERY_VALU_PER_TEST
-        return {"kernel": "ball query %dx%d, radii %s, nsample %s, %d scenes/launch" % (m, n, list(radii), list(nss), b),
+        return {"kernel": "ball query (%s) %dx%d, radii %s, nsample %s, %d scenes/call" % (path, m, n, list(radii), list(nss), b),
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
                 "traffic": pmc_traffic("pda::ball_query %dx%d r%d b%d" % (m, n, len(radii), b), ["ball_query.hip"]),
                 "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg,
                 "distance_tests_per_launch": tests, "tests_per_s": tests / t,
                 "valu_bound_tests_per_s": peak_tests, "valu_frac": tests / t / peak_tests,
                 "note": "bytes per SURVEY 8(d) (xyz streamed once per 256 centres, per radius); tests = M*N per "
-                        "radius (the brute-force count -- a spatially binned kernel performs fewer and can exceed "
-                        "valu_frac 1); VALU bound = 256 CUs x 64 lanes x 2.4 GHz / 7 instructions per test"}
+                        "radius = the brute-force count (the cell-list path performs far fewer, so its valu_frac is an "
+                        "equivalent rate and may exceed 1); VALU bound = 256 CUs x 64 lanes x 2.4 GHz / 7 instructions per "
+                        "test; the cell-list call is 5 launches (grid, count, scan, scatter, query) timed together"}
 
     def roofline_wgrad(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops

@@ -100,6 +100,15 @@ int pda_ball_query_dilated(const float *new_xyz, const float *xyz, int32_t *idx,
  * the Python mirror raises.  idx would be (b,m,nsample), allocated by the caller here. */
 int pda_ellipsoid_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
                         float e1, float e2, float e3, int nsample, pda_stream_t stream);
+/* MI355X extension: pda_ball_query_multi through a uniform cell list (csrc/ball_query_cells.hip) -- the same rows,
+ * bit for bit, computed from the points of the 27 cells around a centre instead of all n (bin -> one wave per centre
+ * -> the nsample smallest indices of its hits; a dense ball falls back to the reference's ascending scan with early
+ * exit).  Worth it for n >= 8192.  scratch: pda_ball_query_cells_scratch_bytes(b, n) bytes, 256-byte aligned, owned
+ * by the caller (nothing is allocated inside); nsample <= 128, radius > 0. */
+int64_t pda_ball_query_cells_scratch_bytes(int b, int n);
+int pda_ball_query_cells(const float *new_xyz, const float *xyz, int32_t *const *idx, int b, int n, int m, int nr,
+                         const float *radii, const int32_t *nsamples, void *scratch, int64_t scratch_bytes,
+                         pda_stream_t stream);
 /* MI355X extension (no reference counterpart): up to 3 radii over the SAME centres and
  * points in one pass -- the multi-scale groupers call ball_query once per scale
  * (pointnet2_modules.py:1657).  idx[i] is (b,m,nsamples[i]); results are identical to

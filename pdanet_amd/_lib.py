@@ -29,6 +29,9 @@ SIGNATURES = {
     "pda_ball_query": [_vp, _vp, _vp, _i, _i, _i, _f, _i, _vp],
     "pda_ball_query_dilated": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _i, _vp],
     "pda_ellipsoid_query": [_vp, _vp, _vp, _i, _i, _i, _f, _f, _f, _i, _vp],
+    "pda_ball_query_cells_scratch_bytes": [_i, _i],
+    "pda_ball_query_cells": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i, ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int32),
+                             _vp, ctypes.c_int64, _vp],
     "pda_ball_query_multi": [_vp, _vp, ctypes.POINTER(_vp), _i, _i, _i, _i,
                              ctypes.POINTER(_f), ctypes.POINTER(ctypes.c_int32), _vp],
     "pda_group_points": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -127,6 +130,7 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _i
     lib.pda_nms_mask_words.restype = ctypes.c_int64
+    lib.pda_ball_query_cells_scratch_bytes.restype = ctypes.c_int64
     lib.pda_bn_relu_scratch_bytes.restype = ctypes.c_int64
     lib.pda_layer_norm_scratch_bytes.restype = ctypes.c_int64
     lib.pda_linear_wgrad_scratch_bytes.restype = ctypes.c_int64

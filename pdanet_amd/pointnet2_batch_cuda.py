@@ -108,6 +108,27 @@ def ball_query_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
     return 1
 
 
+def ball_query_cells_scratch_bytes(b, n):
+    return int(_lib.load().pda_ball_query_cells_scratch_bytes(int(b), int(n)))
+
+
+def ball_query_cells(b, n, m, radii, nsamples, new_xyz, xyz, idxs, scratch):
+    """MI355X extension: ball_query_multi through a uniform cell list (csrc/ball_query_cells.hip); identical rows.
+    scratch: uint8 tensor of ball_query_cells_scratch_bytes(b, n) bytes."""
+    nr = len(radii)
+    assert nr == len(nsamples) == len(idxs)
+    _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(xyz, b * n * 3, "xyz")
+    ptrs = (ctypes.c_void_p * nr)()
+    for i, (t, ns) in enumerate(zip(idxs, nsamples)):
+        _numel_ok(t, b * m * ns, "idx[%d]" % i)
+        ptrs[i] = _chk(t, "idx[%d]" % i, I32)
+    r = (ctypes.c_float * nr)(*[float(x) for x in radii])
+    s = (ctypes.c_int32 * nr)(*[int(x) for x in nsamples])
+    _call("pda_ball_query_cells", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32), ptrs, b, n, m, nr, r, s,
+          _chk(scratch, "scratch", torch.uint8), scratch.numel())
+    return 1
+
+
 def group_points_wrapper(b, c, n, npoints, nsample, points, idx, out):
     _numel_ok(points, b * c * n, "points"); _numel_ok(idx, b * npoints * nsample, "idx")
     _numel_ok(out, b * c * npoints * nsample, "out")

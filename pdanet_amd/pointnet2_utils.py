@@ -1031,6 +1031,12 @@ class BallQueryDilated(Function):
 ball_query_dilated = BallQueryDilated.apply
 
 
+# cell-list ball query (csrc/ball_query_cells.hip) for the multi-scale groupers when the cloud is large enough to pay
+# for the binning passes; below that the scalar-stream brute force of csrc/ball_query.hip is faster
+BALL_QUERY_CELLS = True
+BALL_QUERY_CELLS_MIN_N = 16384      # profiles/r02_ball_query_cells.txt: break-even at 8192, 1.7x at 16384, 3.5-5.4x at 65536
+
+
 def ball_query_multi(radii: List[float], nsamples: List[int], xyz: torch.Tensor,
                      new_xyz: torch.Tensor) -> List[torch.Tensor]:
     """MI355X extension: the multi-scale groupers' ball queries (one per scale over the same
@@ -1044,7 +1050,11 @@ def ball_query_multi(radii: List[float], nsamples: List[int], xyz: torch.Tensor,
         for start in range(0, len(radii), 3):
             rs, nss = radii[start:start + 3], nsamples[start:start + 3]
             idxs = [torch.zeros((B, npoint, ns), dtype=torch.int32, device=xyz.device) for ns in nss]
-            pointnet2.ball_query_multi(B, N, npoint, rs, nss, new_xyz, xyz, idxs)
+            if BALL_QUERY_CELLS and N >= BALL_QUERY_CELLS_MIN_N and max(nss) <= 128 and min(rs) > 0:
+                scratch = torch.empty((pointnet2.ball_query_cells_scratch_bytes(B, N),), dtype=torch.uint8, device=xyz.device)
+                pointnet2.ball_query_cells(B, N, npoint, rs, nss, new_xyz, xyz, idxs, scratch)
+            else:
+                pointnet2.ball_query_multi(B, N, npoint, rs, nss, new_xyz, xyz, idxs)
             out.extend(idxs)
     return out
 
