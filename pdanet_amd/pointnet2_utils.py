@@ -12,6 +12,8 @@ the kernels underneath are the hand-written gfx950 ones reached through the C AB
 import weakref
 from typing import List, Tuple
 
+import os
+
 import torch
 import torch.nn as nn
 from torch.autograd import Function
@@ -1034,7 +1036,7 @@ ball_query_dilated = BallQueryDilated.apply
 # cell-list ball query (csrc/ball_query_cells.hip) for the multi-scale groupers when the cloud is large enough to pay
 # for the binning passes; below that the scalar-stream brute force of csrc/ball_query.hip is faster
 BALL_QUERY_CELLS = True
-BALL_QUERY_CELLS_MIN_N = 16384      # profiles/r02_ball_query_cells.txt: break-even at 8192, 1.7x at 16384, 3.5-5.4x at 65536
+BALL_QUERY_CELLS_MIN_N = int(os.environ.get('PDA_BQ_CELLS_MIN_N', '16384'))      # profiles/r02_ball_query_cells.txt: break-even at 8192, 1.7x at 16384, 3.5-5.4x at 65536
 
 
 def ball_query_multi(radii: List[float], nsamples: List[int], xyz: torch.Tensor,

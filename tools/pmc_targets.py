@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""One hot kernel (or operator call) of the bench, launched a few times, as the program under `rocprofv3 --pmc`
+(tools/pmc_passes.sh).  Targets and the bench keys they feed (benchmarks/workloads.py pmc_record):
+  fps          FPS 16384 -> 4096, 2 scenes                  -> traffic["pda::fps_pruned_kernel FPS 16384->4096 b2"]
+  ball_query   layer-0 ball query 16384 x 16384, 2 radii    -> traffic["pda::ball_query 16384x16384 r2 b2"]
+  wgrad        dW(512x512) over 131072 tokens               -> traffic[...], mfma_util["pda::wgrad_kernel ..."]
+  sa_mlp       fused SA scale 259->256->512->512, ns 64     -> mfma_util["pda::sa_mlp_kernel ..."]
+Inputs are the bench's (synth scene config_id 2, distribution L)."""
+import sys
+
+import torch
+
+sys.path.insert(0, '.')
+from pdanet_amd import pointnet2_batch_cuda as ext, pointnet2_utils as pu, synth  # noqa: E402
+
+target, reps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dev = torch.device("cuda:0")
+xyz = torch.from_numpy(synth.batch_xyz(2, 16384, config_id=2, dist="L")).to(dev)
+if target == "fps":
+    idx = torch.zeros((2, 4096), dtype=torch.int32, device=dev)
+    for _ in range(reps):
+        temp = torch.full((2, 16384), 1e10, device=dev)
+        ext.farthest_point_sampling_wrapper(2, 16384, 4096, xyz, temp, idx)
+elif target == "ball_query":
+    for _ in range(reps):
+        pu.ball_query_multi([0.2, 0.8], [16, 32], xyz, xyz)
+elif target == "wgrad":
+    t, ni, no = 131072, 512, 512
+    x, g = torch.randn(t, ni, device=dev), torch.randn(t, no, device=dev)
+    gw, gb = torch.empty(no, ni, device=dev), torch.empty(no, device=dev)
+    for _ in range(reps):
+        ext.linear_wgrad(x, g, gw, gb, t, ni, no)
+elif target == "sa_mlp":
+    from pdanet_amd import fused_ops
+    from pdanet_amd.pointnet2_modules import PointnetSAModuleMSG_WithSampling
+    layer = PointnetSAModuleMSG_WithSampling(npoint_list=[1024], sample_range_list=[-1], sample_type_list=["D-FPS"], radii=[12.8],
+                                             nsamples=[64], mlps=[[256, 256, 512, 512]], use_xyz=True, dilated_group=False,
+                                             aggregation_mlp=None, confidence_mlp=None, num_class=5).to(dev).eval()
+    fused_ops.enable_fused(layer)
+    pts = xyz[:, :2048].contiguous()
+    feats = torch.randn(2, 256, 2048, device=dev)
+    with torch.no_grad():
+        for _ in range(reps):
+            layer(pts, feats, None, ctr_xyz=pts[:, :1024].contiguous())
+else:
+    raise SystemExit("unknown target " + target)
+torch.cuda.synchronize()
