@@ -23,4 +23,4 @@ for t in wgrad sa_mlp; do
     run mfma_busy_$t SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE $t
 done
 python3 tools/pmc_summarize.py "$DST"
-rm -rf "$OUT"
+rm -rf "$OUT"; mkdir -p gpurun_out/profiles; cp -r "$DST" gpurun_out/profiles/
