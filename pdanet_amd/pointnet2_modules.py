@@ -382,7 +382,7 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
         sampled_idx_list = []
         if ctr_xyz is None:
             if presampled is not None:
-                sampled_idx_list, new_xyz = presampled
+                sampled_idx_list, new_xyz = presampled[0], presampled[1]
             else:
                 sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
                                                  self.sample_range_list, self.npoint_list)
@@ -532,8 +532,10 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 new_xyz=None, ctr_xyz=None, presampled=None):
         sampled_idx_list = []
         if ctr_xyz is None:
+            prequery = None
             if presampled is not None:
-                sampled_idx_list, new_xyz = presampled
+                sampled_idx_list, new_xyz = presampled[0], presampled[1]
+                prequery = presampled[2] if len(presampled) > 2 else None
             else:
                 sampled_idx_list = sample_points(xyz, features, cls_features, self.sample_type_list,
                                                  self.sample_range_list, self.npoint_list)
@@ -542,12 +544,13 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             new_xyz_feature = pointnet2_utils.gather_operation(features, sampled_idx_list).transpose(1, 2).contiguous()
         else:
             new_xyz = ctr_xyz  # the reference has no centre features on this branch either (:850-851)
+            prequery = None
 
         directional = len(self.groupers) > 0 and isinstance(
             self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional)
         if len(self.groupers) > 0 and directional and CHANNELS_LAST and getattr(self, "channels_last", True) \
                 and xyz.is_cuda and self.groupers[0].use_xyz and features is not None:
-            return self._forward_channels_last(xyz, features, new_xyz, new_xyz_feature, sampled_idx_list)
+            return self._forward_channels_last(xyz, features, new_xyz, new_xyz_feature, sampled_idx_list, prequery)
 
         if len(self.groupers) > 0:
             new_features_list = []
@@ -598,21 +601,48 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         return new_xyz, new_features, cls_features, sampled_idx_list
 
 
-    def _forward_channels_last(self, xyz, features, new_xyz, new_xyz_feature, sampled_idx_list):
+    def ragged_capable(self, features=None):
+        """The unique-token encoder applies to this layer (shapes the kernels are built for, switches on)."""
+        if len(self.groupers) == 0 or not isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional):
+            return False
+        probe = features if features is not None else next(self.parameters())
+        return (pointnet2_utils.RaggedTransformerBlock.supported(self.Local_pointformer[0].self_attn.embed_dim,
+                                                                 self.Local_pointformer[0].self_attn.num_heads, max(self.nsamples), probe)
+                and all(ns in pointnet2_utils.GroupAttention.SUPPORTED_SEQ for ns in self.nsamples)
+                and FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL
+                and not torch.cuda.is_current_stream_capturing())    # the plan's token count is read on the host
+
+    def prequery(self, xyz, new_xyz):
+        """Everything of this layer that depends on coordinates only, for the sampling side stream of the backbone: the
+        neighbour lists of all scales and, when the unique-token encoder applies, their plans with the token counts on
+        their way to pinned host memory (no synchronisation here)."""
+        idxs = self._ball_queries(xyz, new_xyz)
+        out = {'idxs': idxs, 'parts': None, 'totals': None}
+        if self.ragged_capable():
+            parts, totals = pointnet2_utils.ragged_plan_parts(idxs)
+            pinned = torch.empty((len(parts),), dtype=torch.int32, pin_memory=True)
+            pinned.copy_(totals, non_blocking=True)
+            out.update(parts=parts, totals=pinned)
+        return out
+
+    def _forward_channels_last(self, xyz, features, new_xyz, new_xyz_feature, sampled_idx_list, prequery=None):
         """The PDA scale loop of forward() in the point-major layout (see CHANNELS_LAST note):
         grouped tensors are (B, npoint, nsample, C); same parameters and math as the
         channel-major branch below / the reference (:854-945)."""
         B, npoint = new_xyz.shape[0], new_xyz.shape[1]
-        idxs = self._ball_queries(xyz, new_xyz)
-        # distinct-token plans of all scales (ONE host synchronisation per layer); None: run this scale dense
-        plans = [None] * len(idxs)
-        C0 = features.shape[1]
-        if pointnet2_utils.RaggedTransformerBlock.supported(4 * C0, self.Local_pointformer[0].self_attn.num_heads,
-                                                            max(self.nsamples), features) \
-                and all(ns in pointnet2_utils.GroupAttention.SUPPORTED_SEQ for ns in self.nsamples) \
-                and FUSED_TRANSFORMER_BLOCK and FUSED_LAYER_NORM and GROUP_ATTENTION_KERNEL \
-                and not torch.cuda.is_current_stream_capturing():    # the plan's token count is read on the host
-            plans = [p if p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in pointnet2_utils.ragged_plans(idxs)]
+        # neighbour lists and distinct-token plans of all scales; None: run that scale dense.  Computed ahead of time on the
+        # sampling side stream when the centres depend on coordinates only (`prequery`, whose event the caller has waited
+        # for on this stream and on the host), otherwise here with ONE host synchronisation for the layer
+        plans = [None] * len(self.groupers)
+        if prequery is not None:
+            idxs = prequery['idxs']
+            if prequery['parts'] is not None and self.ragged_capable(features):
+                plans = pointnet2_utils.ragged_plans_from(prequery['parts'], prequery['totals'].tolist())
+        else:
+            idxs = self._ball_queries(xyz, new_xyz)
+            if self.ragged_capable(features):
+                plans = pointnet2_utils.ragged_plans(idxs)
+        plans = [p if p is not None and p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in plans]
         feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
         global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)
         centre = new_xyz.unsqueeze(2)                                         # (B, M, 1, 3)

@@ -803,10 +803,9 @@ class RaggedPlan:
         return self.tokens / float(self.groups * self.nsample)
 
 
-def ragged_plans(idxs):
-    """One RaggedPlan per neighbour-index tensor (B, M, ns) of a layer.  ONE host synchronisation for all of them: the
-    token counts size the GEMMs of the encoder (the reference's backbone synchronises once per forward as well,
-    IASSD_backbone.py:134-137)."""
+def ragged_plan_parts(idxs):
+    """Device half of ragged_plans: per index tensor (cnt, off, rowmap, groups, nsample) and the stacked token counts
+    (a device tensor).  No synchronisation."""
     parts = []
     for idx in idxs:
         G, ns = idx.shape[0] * idx.shape[1], idx.shape[2]
@@ -815,8 +814,20 @@ def ragged_plans(idxs):
         rowmap = torch.empty((G * ns,), dtype=torch.int32, device=idx.device)
         pointnet2.ragged_plan(idx, cnt, off, rowmap, G, ns)
         parts.append((cnt, off, rowmap, G, ns))
-    totals = torch.stack([p[1][-1] for p in parts]).tolist()
+    return parts, torch.stack([p[1][-1] for p in parts])
+
+
+def ragged_plans_from(parts, totals):
     return [RaggedPlan(c, o, r[:u], int(u), G, ns) for (c, o, r, G, ns), u in zip(parts, totals)]
+
+
+def ragged_plans(idxs):
+    """One RaggedPlan per neighbour-index tensor (B, M, ns) of a layer.  ONE host synchronisation for all of them: the
+    token counts size the GEMMs of the encoder (the reference's backbone synchronises once per forward as well,
+    IASSD_backbone.py:134-137).  A layer whose centres depend on coordinates only gets its plans ahead of time on the
+    sampling side stream instead (backbone._presample), with the counts copied to pinned memory."""
+    parts, totals = ragged_plan_parts(idxs)
+    return ragged_plans_from(parts, totals.tolist())
 
 
 class AssembleTokensRagged(Function):
