@@ -81,11 +81,21 @@ class KernelTimers:
     on (torch events record on the CURRENT stream, and the ops launch on the current stream -- for the D-FPS
     prefetch that is the side stream of backbone._presample).  Active only while `record` is set."""
 
+    @property
+    def record(self):
+        return self._record
+
+    @record.setter
+    def record(self, on):
+        from pdanet_amd import pointnet2_utils as pu
+        self._record = bool(on)
+        pu.SA_MFMA_EVENTS = self.sa_mfma_events if on else None     # the SA group-MLP launches time themselves
+
     def _install_timers(self):
         from pdanet_amd import pointnet2_utils as pu
         wl = self
+        self.fps_events, self.bq_events, self.wgrad_events, self.sa_mfma_events = [], [], [], []
         self.record = False
-        self.fps_events, self.bq_events, self.wgrad_events = [], [], []
 
         def timed(orig, sink, describe):
             def f(*a):
@@ -158,6 +168,25 @@ class KernelTimers:
                         "radius = the brute-force count (the cell-list path performs far fewer, so its valu_frac is an "
                         "equivalent rate and may exceed 1); VALU bound = 256 CUs x 64 lanes x 2.4 GHz / 7 instructions per "
                         "test; the cell-list call is 5 launches (grid, count, scan, scatter, query) timed together"}
+
+    def roofline_sa_mlp_train(self):
+        """The vanilla-SA group MLPs in training form on lin_cols_kernel (forward and input-gradient contractions of ONCE
+        layers 0 and 5; the weight gradients are wgrad_kernel launches and appear in roofline_mfma): algorithmic flops of
+        all launches of the timed region / their summed duration."""
+        if not self.sa_mfma_events:
+            return None
+        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.sa_mfma_events) * 1e-3
+        fl = sum(f for _, _, f in self.sa_mfma_events)
+        steps = max(1, len(self.fps_events))
+        util = pmc_record("mfma_util", "pda::lin_cols_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
+        return {"kernel": "lin_cols_kernel (SA group MLP, training form: %d launches per step, forward + input gradient)" % (
+                    len(self.sa_mfma_events) // steps),
+                "bound": "mfma", "achieved": fl / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": fl / t / 1e12 / F32_MFMA_PEAK_TF, "traffic": None, "ms_per_step": t / steps * 1e3,
+                "gflop_per_step": fl / steps / 1e9, "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
+                "note": "v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction; "
+                        "SURVEY 8(d): the layer-5 chain is 86.1 GFLOP per scene forward, the input gradients of layers 2-3 "
+                        "add 77.5 (layer 1's 259-column input gradient stays on the library)"}
 
     def roofline_wgrad(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
@@ -312,7 +341,7 @@ class BackboneWorkload(KernelTimers):
 
     def rooflines(self):
         return {"roofline": self.roofline_fps(), "roofline_ball_query": self.roofline_ball_query(),
-                "roofline_mfma": self.roofline_wgrad()}
+                "roofline_mfma": self.roofline_wgrad(), "roofline_mfma_sa_mlp": self.roofline_sa_mlp_train()}
 
     @staticmethod
     def loss_of(bd):

@@ -202,6 +202,24 @@ int pda_sa_mlp_maxpool(const float *xyz, const float *new_xyz, const float *feat
                        const int32_t *idx, float *out, int b, int n, int m, int c, int nsample,
                        const int32_t *dims, const float *const *wf, const float *const *scale,
                        const float *const *shift, pda_stream_t stream);
+/* Training form of the group MLP (csrc/sa_mlp.hip, lin_cols_kernel): training-mode BatchNorm separates the layers, so
+ * the chain runs one contraction per call on the same f32 MFMA code -- forward and input gradient; the statistics,
+ * ReLU and max-pool are pda_bn_relu_* (include/pda_train.h), the weight gradient pda_linear_wgrad.
+ *   pda_linear_cols:       y (tokens, n_out) = x (tokens, k) W^T;  k in {256, 512}, n_out a multiple of 128 <= 1024;
+ *                          wf = W (n_out, k) packed by pda_linear_cols_pack(..., transposed_source = 0, gather_order = 0).
+ *                          dX = dY W is the same call with wf packed from the transposed source (W given as stored,
+ *                          (k_out = rows of W, n = its columns): pack(w, wf, n_out = cols of W, k = rows of W, 1, 0)).
+ *   pda_sa_gather_linear:  layer 1 with the grouping fused in (QueryAndGroup, pointnet2_utils.py:671-704): y (b, m, ns,
+ *                          n_out) = [xyz[idx] - new_xyz | feats_pm[idx]] W1^T with feats_pm (b, n, c) POINT-major, c = 256,
+ *                          W1 (n_out, 3 + c) packed with gather_order = 1.  The grouped input is never materialised.
+ * PDA_ERR_UNSUPPORTED for other shapes (callers use the library GEMM). */
+int pda_linear_cols_packed_size(int n_out, int k);
+int pda_linear_cols_pack(const float *w, float *wf, int n_out, int k, int transposed_source, int gather_order,
+                         pda_stream_t stream);
+int pda_linear_cols(const float *x, const float *wf, float *y, int64_t tokens, int k, int n_out, pda_stream_t stream);
+int pda_sa_gather_linear(const float *xyz, const float *new_xyz, const float *feats_pm, const int32_t *idx,
+                         const float *wf, float *y, int b, int n, int m, int c, int nsample, int n_out,
+                         pda_stream_t stream);
 /* Number of floats pda_sa_mlp_pack_weights writes for a (rows x cols) layer. */
 int pda_sa_mlp_packed_size(int rows, int cols, int first_layer);
 /* Re-orders a row-major (rows x cols) fp32 weight matrix into MFMA A-fragment order. */

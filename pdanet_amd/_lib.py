@@ -49,6 +49,10 @@ SIGNATURES = {
     "pda_group_attention_bwd_bf16": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_sa_mlp_maxpool": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, ctypes.POINTER(ctypes.c_int32),
                            ctypes.POINTER(_vp), ctypes.POINTER(_vp), ctypes.POINTER(_vp), _vp],
+    "pda_linear_cols_packed_size": [_i, _i],
+    "pda_linear_cols_pack": [_vp, _vp, _i, _i, _i, _i, _vp],
+    "pda_linear_cols": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_sa_gather_linear": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],
     "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
     # include/pda_train.h

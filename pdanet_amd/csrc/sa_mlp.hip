@@ -39,8 +39,10 @@ constexpr int SA_CH = 4;  // output row blocks (of 32 rows) accumulated at a tim
 // W[rb*32 + (lane&31)][k(4*tq + e, lane>>5)].
 //   mode 0 (first layer, input gathered):   k(t, h) = 2 t + h
 //   mode 1 (input = previous accumulator):  k(t, h) = 32 (t / 16) + ((t%16)&3) + 8 ((t%16)>>2) + 4 h
+//   mode 2 (input = rows of a (tokens, K) matrix read as float4 chunks): k(t, h) = 8 (t / 4) + 4 h + (t % 4)
+// trans: the source is the TRANSPOSE of the matrix to pack (w is (cols, rows) row-major): input-gradient GEMMs.
 __global__ void sa_mlp_pack_kernel(const float* __restrict__ w, float* __restrict__ wf, int rows, int cols,
-                                   int R, int KS, int mode) {
+                                   int R, int KS, int mode, int trans = 0) {
     const int total = (KS / 4) * R * 64 * 4;
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < total; o += gridDim.x * blockDim.x) {
         const int e = o & 3, lane = (o >> 2) & 63, rest = o >> 8;
@@ -49,8 +51,9 @@ __global__ void sa_mlp_pack_kernel(const float* __restrict__ w, float* __restric
         const int row = rb * 32 + (lane & 31);
         int k;
         if (mode == 0) k = 2 * t + h;
+        else if (mode == 2) k = 8 * (t >> 2) + 4 * h + (t & 3);
         else { const int tt = t & 15; k = 32 * (t >> 4) + (tt & 3) + 8 * (tt >> 2) + 4 * h; }
-        wf[o] = (row < rows && k < cols) ? w[(size_t)row * cols + k] : 0.f;
+        wf[o] = (row < rows && k < cols) ? (trans ? w[(size_t)k * rows + row] : w[(size_t)row * cols + k]) : 0.f;
     }
 }
 
@@ -132,6 +135,44 @@ __device__ __forceinline__ void gemm_chunk(f32x16 (&acc)[CH], const HinT& hin, c
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < CH; ++r) cur[r][u] = nxt[r][u];
+    }
+}
+
+// gemm_chunk with a RUN-TIME number of row blocks R (training-form kernels: one instantiation per K serves every width);
+// the k loop stays fully unrolled -- the B operand is a register array and must be indexed statically.
+template <int KS, int CH, typename HinT>
+__device__ __forceinline__ void gemm_chunk_rt(f32x16 (&acc)[CH], const HinT& hin, const float* __restrict__ wf, int R,
+                                               int rb0, int lane) {
+    constexpr int TQ = KS / 4;
+#pragma unroll
+    for (int r = 0; r < CH; ++r)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+    float4 cur[CH], nxt[CH];
+    const float* base = wf + ((size_t)rb0 * 64 + lane) * 4;
+    const size_t step = (size_t)R * 64 * 4;
+#pragma unroll
+    for (int r = 0; r < CH; ++r) cur[r] = *reinterpret_cast<const float4*>(base + (size_t)r * 256);
+#pragma unroll
+    for (int tq = 0; tq < TQ; ++tq) {
+        if (tq + 1 < TQ) {
+#pragma unroll
+            for (int r = 0; r < CH; ++r) nxt[r] = *reinterpret_cast<const float4*>(base + (size_t)(tq + 1) * step + (size_t)r * 256);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float b = hin(tq * 4 + e);
+#pragma unroll
+            for (int r = 0; r < CH; ++r) {
+                const float4 a4 = cur[r];
+                const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
+                acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < CH; ++r) cur[r] = nxt[r];
     }
 }
 
@@ -269,6 +310,82 @@ void sa_mlp_kernel(const SaMlpParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Training form (round 2): the group MLP's GEMMs one layer at a time on the same MFMA machinery.
+// Training-mode BatchNorm needs the statistics of a layer's pre-activation before the next layer can start, so the
+// chain cannot stay in registers (DESIGN.md "The vanilla SA group MLP in training mode"); what can be done is to run
+// every contraction of the chain -- forward and input gradient -- on this file's f32 MFMA code instead of a library:
+//   lin_cols_kernel<KS, GATHER = false>:  Y (T, N) = X (T, K) W^T, X rows read as float4 chunks straight into the
+//       B-operand registers (k order "mode 2"), weights pre-packed in that order (also from W^T for dX = dY W);
+//   lin_cols_kernel<KS0, GATHER = true>:  layer 1 with the grouping fused in: X is never built, the wave gathers
+//       [xyz[idx] - centre | features[idx]] of its 32 (centre, sample) columns into registers as sa_mlp_kernel does.
+// A wave owns 32 tokens and streams the whole packed weight matrix from L2 (4 waves of a workgroup read the same
+// fragments); output rows leave as 16-byte stores.  The statistics, normalisation, ReLU and max-pool stay in
+// csrc/bn_relu.hip, the weight gradient in csrc/wgrad.hip.
+struct LinColsParams {
+    const float* x;         // (T, K) row-major                         (GATHER: unused)
+    const float* wf;        // packed weights
+    float* y;               // (T, N) row-major
+    int64_t tokens;
+    int k, n_out, R;        // R = ceil(n_out / 32)
+    // GATHER
+    const float* xyz; const float* new_xyz; const float* feat_pm; const int32_t* idx;
+    int n, m, c, ns;
+};
+
+// Up to two waves per SIMD where the registers allow it (K = 256: 166 VGPRs): one wave's strided operand loads and
+// output stores then run under the other's MFMA chain.
+template <int KS, bool GATHER>
+__global__ __launch_bounds__(SA_WAVES * 64) __attribute__((amdgpu_waves_per_eu(1, 2)))
+void lin_cols_kernel(const LinColsParams p) {
+    const int w = wave_id();
+    const int lane = lane_id();
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t tok = ((int64_t)blockIdx.x * SA_WAVES + w) * 32 + j;
+    const bool valid = tok < p.tokens;
+    const int64_t tk = valid ? tok : 0;
+    float x[KS];
+    if constexpr (!GATHER) {
+        const float* row = p.x + tk * p.k + 4 * h;
+#pragma unroll
+        for (int q = 0; q < KS / 4; ++q) {
+            const float4 v = *reinterpret_cast<const float4*>(row + 8 * q);
+            x[4 * q] = valid ? v.x : 0.f; x[4 * q + 1] = valid ? v.y : 0.f; x[4 * q + 2] = valid ? v.z : 0.f; x[4 * q + 3] = valid ? v.w : 0.f;
+        }
+    } else {
+        // token = (scene, centre, sample); k order of mode 0: k = 2 t + h; k = 0..2 centred xyz, k = 3 + ch features
+        const int64_t per_scene = (int64_t)p.m * p.ns;
+        const int bs = (int)(tk / per_scene);
+        const int centre = (int)((tk - bs * per_scene) / p.ns);
+        const int id = p.idx[tk];
+        const float* pt = p.xyz + ((size_t)bs * p.n + id) * 3;
+        const float* ct = p.new_xyz + ((size_t)bs * p.m + centre) * 3;
+        const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];     // pointnet2_utils.py:692
+        const float* f = p.feat_pm + ((size_t)bs * p.n + id) * p.c;                 // point-major row of the neighbour
+        x[0] = valid ? (h == 0 ? dx : dy) : 0.f;
+        x[1] = valid ? (h == 0 ? dz : (0 < p.c ? f[0] : 0.f)) : 0.f;
+#pragma unroll
+        for (int t = 2; t < KS; ++t) {
+            const int ch = 2 * t + h - 3;
+            x[t] = (valid && ch < p.c) ? f[ch] : 0.f;
+        }
+    }
+    const X0Reader<KS> rd{x};
+    float* yrow = p.y + tk * p.n_out;
+    for (int rb0 = 0; rb0 < p.R; rb0 += SA_CH) {
+        f32x16 acc[SA_CH];
+        gemm_chunk_rt<KS, SA_CH>(acc, rd, p.wf, p.R, rb0, lane);    // n_out % 128 == 0 (launcher): whole chunks only
+        if (valid) {
+#pragma unroll
+            for (int r = 0; r < SA_CH; ++r)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    *reinterpret_cast<float4*>(yrow + (rb0 + r) * 32 + 8 * q + 4 * h) =
+                        make_float4(acc[r][4 * q], acc[r][4 * q + 1], acc[r][4 * q + 2], acc[r][4 * q + 3]);
+        }
+    }
+}
+
 template <int KS0, int R1, int R2, int R3>
 static int launch_sa_mlp(const SaMlpParams& p, int b, hipStream_t stream) {
     const int ns = p.ns;
@@ -342,4 +459,56 @@ PDA_API int pda_sa_mlp_maxpool(const float* xyz, const float* new_xyz, const flo
 #undef PDA_SA_CASE
     pda::set_error("pda_sa_mlp_maxpool: no kernel built for chain %d->%d->%d->%d", dims[0], dims[1], dims[2], dims[3]);
     return PDA_ERR_UNSUPPORTED;
+}
+
+// ---- training form: one GEMM of the group MLP per call (see lin_cols_kernel) ----------------------------------------
+PDA_API int pda_linear_cols_packed_size(int n_out, int k) {
+    if (n_out <= 0 || k <= 0) return 0;
+    return pda::divup(k, 8) * 4 * pda::divup(n_out, 32) * 64;   // KS * R * 64 floats, KS = k / 2 rounded to 4 k-steps
+}
+
+PDA_API int pda_linear_cols_pack(const float* w, float* wf, int n_out, int k, int transposed_source, int gather_order,
+                                 pda_stream_t stream) {
+    PDA_REQUIRE(w && wf && n_out > 0 && k > 0, "pda_linear_cols_pack: bad argument");
+    const int R = pda::divup(n_out, 32);
+    const int KS = pda::divup(k, 8) * 4;
+    const int total = KS * R * 64;
+    hipLaunchKernelGGL(pda::sa_mlp_pack_kernel, dim3(pda::divup(total, 256) < 1024 ? pda::divup(total, 256) : 1024), dim3(256), 0,
+                       (hipStream_t)stream, w, wf, n_out, k, R, KS, gather_order ? 0 : 2, transposed_source);
+    return pda::check_launch("pda_linear_cols_pack");
+}
+
+PDA_API int pda_linear_cols(const float* x, const float* wf, float* y, int64_t tokens, int k, int n_out, pda_stream_t stream) {
+    PDA_REQUIRE(tokens >= 0 && k > 0 && n_out > 0, "pda_linear_cols: bad size");
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(x && wf && y && (((uintptr_t)x | (uintptr_t)wf | (uintptr_t)y) & 15) == 0, "pda_linear_cols: null or misaligned pointer");
+    if ((k != 256 && k != 512) || n_out % 128 != 0 || n_out > 1024) {
+        pda::set_error("pda_linear_cols: no kernel built for K=%d, N=%d (K in {256, 512}, N a multiple of 128 <= 1024)", k, n_out);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::LinColsParams p{};
+    p.x = x; p.wf = wf; p.y = y; p.tokens = tokens; p.k = k; p.n_out = n_out; p.R = n_out / 32;
+    const dim3 grid((unsigned)pda::divup64(tokens, pda::SA_WAVES * 32)), block(pda::SA_WAVES * 64);
+    if (k == 256) hipLaunchKernelGGL((pda::lin_cols_kernel<128, false>), grid, block, 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((pda::lin_cols_kernel<256, false>), grid, block, 0, (hipStream_t)stream, p);
+    return pda::check_launch("pda_linear_cols");
+}
+
+PDA_API int pda_sa_gather_linear(const float* xyz, const float* new_xyz, const float* feats_pm, const int32_t* idx, const float* wf,
+                                 float* y, int b, int n, int m, int c, int ns, int n_out, pda_stream_t stream) {
+    PDA_REQUIRE(b >= 0 && n > 0 && m >= 0 && c >= 0 && ns >= 1 && n_out > 0, "pda_sa_gather_linear: bad size");
+    const int64_t tokens = (int64_t)b * m * ns;
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(xyz && new_xyz && idx && wf && y && (feats_pm || c == 0), "pda_sa_gather_linear: null pointer");
+    PDA_REQUIRE((((uintptr_t)wf | (uintptr_t)y) & 15) == 0, "pda_sa_gather_linear: misaligned pointer");
+    if (c != 256 || n_out % 128 != 0 || n_out > 1024) {
+        pda::set_error("pda_sa_gather_linear: no kernel built for C=%d, N=%d (C = 256, N a multiple of 128 <= 1024)", c, n_out);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::LinColsParams p{};
+    p.wf = wf; p.y = y; p.tokens = tokens; p.k = 3 + c; p.n_out = n_out; p.R = n_out / 32;
+    p.xyz = xyz; p.new_xyz = new_xyz; p.feat_pm = feats_pm; p.idx = idx; p.n = n; p.m = m; p.c = c; p.ns = ns;
+    const dim3 grid((unsigned)pda::divup64(tokens, pda::SA_WAVES * 32)), block(pda::SA_WAVES * 64);
+    hipLaunchKernelGGL((pda::lin_cols_kernel<132, true>), grid, block, 0, (hipStream_t)stream, p);
+    return pda::check_launch("pda_sa_gather_linear");
 }

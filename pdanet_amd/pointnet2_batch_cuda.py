@@ -532,3 +532,30 @@ def group_attention_ragged_bwd(qkv, grad_out, lse, cnt, off, grad_qkv, tokens, n
     _call("pda_group_attention_ragged_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32), _chk(lse, "lse", F32),
           _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
     return 1
+
+
+# ---- training form of the vanilla-SA group MLP: one MFMA contraction per call (csrc/sa_mlp.hip, lin_cols_kernel) -----
+def linear_cols_pack(w, n_out, k, transposed_source=False, gather_order=False):
+    """Packed copy of a weight matrix for linear_cols / sa_gather_linear (A-fragment order of the f32 MFMA)."""
+    lib = _lib.load()
+    wf = torch.empty((int(lib.pda_linear_cols_packed_size(int(n_out), int(k))),), dtype=F32, device=w.device)
+    _numel_ok(w, n_out * k, "w")
+    _call("pda_linear_cols_pack", w, _chk(w, "w", F32), _chk(wf, "wf", F32), n_out, k, 1 if transposed_source else 0,
+          1 if gather_order else 0)
+    return wf
+
+
+def linear_cols(x, wf, y, tokens, k, n_out):
+    _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
+    _numel_ok(wf, int(_lib.load().pda_linear_cols_packed_size(int(n_out), int(k))), "wf")
+    _call("pda_linear_cols", x, _chk(x, "x", F32), _chk(wf, "wf", F32), _chk(y, "y", F32), tokens, k, n_out)
+    return 1
+
+
+def sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, b, n, m, c, nsample, n_out):
+    _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(feats_pm, b * n * c, "feats_pm")
+    _numel_ok(idx, b * m * nsample, "idx"); _numel_ok(y, b * m * nsample * n_out, "y")
+    _numel_ok(wf, int(_lib.load().pda_linear_cols_packed_size(int(n_out), 3 + int(c))), "wf")
+    _call("pda_sa_gather_linear", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32), _chk(feats_pm, "feats_pm", F32),
+          _chk(idx, "idx", I32), _chk(wf, "wf", F32), _chk(y, "y", F32), b, n, m, c, nsample, n_out)
+    return 1

@@ -139,9 +139,10 @@ def _linear_relu(x, w, b):
 FUSED_BN_RELU_MAX_POOL = True   # the last BN+ReLU of a grouped MLP and the max over nsample as one autograd node
 
 
-def _mlp_lastdim(layers, x, pool=False):
+def _mlp_lastdim(layers, x, pool=False, mfma=False):
     """[Conv 1x1 -> BN -> ReLU]* of an nn.Sequential applied over the last dim of x; pool=True: followed by the max over
-    dim -2 (the nsample axis of a grouped tensor), fused into the last BN+ReLU in training mode."""
+    dim -2 (the nsample axis of a grouped tensor), fused into the last BN+ReLU in training mode.  mfma=True (the
+    vanilla SA group MLPs): the contractions run on this repo's f32 MFMA kernels where a kernel is built for the shape."""
     layers = list(layers)
     skip = 0
     pooled = False
@@ -162,7 +163,11 @@ def _mlp_lastdim(layers, x, pool=False):
                 continue
             relu_next = k + 2 < len(layers) and isinstance(layers[k + 2], nn.ReLU)
             boundary = isinstance(nxt, (nn.BatchNorm1d, nn.BatchNorm2d)) and relu_next and _bf16_boundary(x, m, nxt)
-            x = pointnet2_utils.linear(x, m.weight.flatten(1), m.bias, out_bf16=boundary)
+            w2d = m.weight.flatten(1)
+            if mfma and m.bias is None and torch.is_grad_enabled() and pointnet2_utils.LinearColsMFMA.supported(x, w2d):
+                x = pointnet2_utils.LinearColsMFMA.apply(x, w2d)     # csrc/sa_mlp.hip, lin_cols_kernel
+            else:
+                x = pointnet2_utils.linear(x, w2d, m.bias, out_bf16=boundary)
         elif isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d)):
             if k + 1 < len(layers) and isinstance(layers[k + 1], nn.ReLU):
                 # dense-bf16 mode: y goes out as bf16 when its only consumer is the next bf16 GEMM of the chain
@@ -406,11 +411,20 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                         new_features_list.append(pooled)
                         continue
                 if use_cl and self.groupers[i].use_xyz:
+                    conv1 = self.mlps[i][0]
+                    w1 = conv1.weight.flatten(1)
+                    if (torch.is_grad_enabled() and isinstance(conv1, nn.Conv2d) and conv1.bias is None
+                            and pointnet2_utils.SaGatherLinear.supported(xyz, feats_pm, w1)):
+                        # grouping fused into the first contraction: the (B, M, ns, 3 + C) tensor is never built
+                        g = pointnet2_utils.SaGatherLinear.apply(xyz, new_xyz, feats_pm, idxs[i], w1)
+                        g = _mlp_lastdim(list(self.mlps[i])[1:], g, pool=True, mfma=True)
+                        new_features_list.append(g.transpose(1, 2))
+                        continue
                     # (B, M, ns, 3 + C): [xyz - centre | features], neighbours gathered as rows
                     g = pointnet2_utils.group_rows(xyz, idxs[i]) - new_xyz.unsqueeze(2)
                     if feats_pm is not None:
                         g = torch.cat([g, pointnet2_utils.group_rows(feats_pm, idxs[i])], dim=-1)
-                    g = _mlp_lastdim(self.mlps[i], g, pool=True)              # (B, M, mlp[-1]): MLP + max over nsample
+                    g = _mlp_lastdim(self.mlps[i], g, pool=True, mfma=True)   # (B, M, mlp[-1]): MLP + max over nsample
                     new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
                     continue
                 if plain_ball:

@@ -784,6 +784,116 @@ def transformer_block(tr, x, pool=False):
                                   tr.linear2.weight, tr.linear2.bias, at.num_heads, tr.norm1.eps, tr.norm2.eps, pool)
 
 
+# ---- training form of the vanilla-SA group MLP on this repo's MFMA code (csrc/sa_mlp.hip, lin_cols_kernel) -----------
+# SA_MFMA_TRAIN: the contractions of the set-abstraction MLPs -- forward and input gradient -- run on the hand-written
+# f32 MFMA kernels instead of the library GEMMs (the weight gradient is csrc/wgrad.hip already); layer 1 gathers its
+# grouped input in the kernel, so the (B, M, ns, 3 + C) tensor only exists in the backward pass.
+SA_MFMA_TRAIN = True
+SA_MFMA_EVENTS = None      # bench: a list collecting (event0, event1, flops) per MFMA launch of the SA group MLPs
+
+
+def _sa_timed(flops, fn):
+    ev = SA_MFMA_EVENTS
+    if ev is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    ev.append((e0, e1, flops))
+
+
+class LinearColsMFMA(Function):
+    """y = x W^T (no bias) over the last dim of x (..., K): forward and input gradient on lin_cols_kernel, weight
+    gradient on csrc/wgrad.hip (or the library below its break-even)."""
+
+    @staticmethod
+    def supported(x, weight):
+        n_out, k = weight.shape
+        return (SA_MFMA_TRAIN and x.is_cuda and x.dtype == torch.float32 and weight.dtype == torch.float32 and k in (256, 512)
+                and n_out % 128 == 0 and n_out <= 1024 and x.shape[-1] == k and not torch.is_autocast_enabled() and not DENSE_BF16)
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        n_out, k = weight.shape
+        x2 = x.contiguous().view(-1, k)
+        T = x2.shape[0]
+        y = torch.empty((T, n_out), dtype=torch.float32, device=x.device)
+        wf = pointnet2.linear_cols_pack(weight.contiguous(), n_out, k)
+        _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(x2, wf, y, T, k, n_out))
+        ctx.save_for_backward(x2, weight)
+        ctx.x_shape = x.shape
+        return y.view(*x.shape[:-1], n_out)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        x2, weight = ctx.saved_tensors
+        n_out, k = weight.shape
+        g2 = grad_out.contiguous().view(-1, n_out)
+        T = g2.shape[0]
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            if n_out in (256, 512) and k % 128 == 0:
+                gx = torch.empty((T, k), dtype=torch.float32, device=g2.device)
+                # dX = dY W: the same kernel with the weights packed from the transposed source
+                wft = pointnet2.linear_cols_pack(weight.contiguous(), k, n_out, transposed_source=True)
+                _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(g2, wft, gx, T, n_out, k))
+            else:
+                gx = g2.mm(weight)
+            gx = gx.view(ctx.x_shape)
+        if ctx.needs_input_grad[1]:
+            gw = _wgrad(x2, g2, weight, False)[0]
+        return gx, gw
+
+
+class SaGatherLinear(Function):
+    """Layer 1 of a vanilla SA scale with the grouping fused in: z1 (B, M, ns, C1) = [xyz[idx] - new_xyz | feats[idx]] W1^T
+    (QueryAndGroup + the first 1x1 convolution, pointnet2_utils.py:671-704 + pointnet2_modules.py:1657).  The grouped
+    input is rebuilt only in the backward pass (weight gradient), where the input gradient goes through the library
+    (3 + C = 259 columns) and on to the features (scatter-add) and the centres."""
+
+    @staticmethod
+    def supported(xyz, feats_pm, weight):
+        return (SA_MFMA_TRAIN and xyz.is_cuda and feats_pm is not None and feats_pm.dtype == torch.float32 and feats_pm.shape[-1] == 256
+                and weight.shape[1] == 259 and weight.shape[0] % 128 == 0 and weight.shape[0] <= 1024
+                and not torch.is_autocast_enabled() and not DENSE_BF16)
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, weight):
+        B, N, _ = xyz.shape
+        M, ns = idx.shape[1], idx.shape[2]
+        C, n_out = feats_pm.shape[-1], weight.shape[0]
+        xyz, new_xyz, feats_pm = xyz.contiguous(), new_xyz.contiguous(), feats_pm.contiguous()
+        y = torch.empty((B, M, ns, n_out), dtype=torch.float32, device=xyz.device)
+        wf = pointnet2.linear_cols_pack(weight.contiguous(), n_out, 3 + C, gather_order=True)
+        _sa_timed(2.0 * B * M * ns * (3 + C) * n_out,
+                  lambda: pointnet2.sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, B, N, M, C, ns, n_out))
+        ctx.save_for_backward(xyz, new_xyz, feats_pm, idx, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xyz, new_xyz, feats_pm, idx, weight = ctx.saved_tensors
+        B, M, ns = idx.shape
+        n_out = weight.shape[0]
+        g2 = grad_out.contiguous().view(-1, n_out)
+        g_new = g_feats = gw = None
+        with torch.no_grad():
+            if ctx.needs_input_grad[4]:
+                x0 = torch.cat([group_rows(xyz, idx) - new_xyz.unsqueeze(2), group_rows(feats_pm, idx)], dim=-1).view(-1, weight.shape[1])
+                gw = _wgrad(x0, g2, weight, False)[0]
+                del x0
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                gx0 = g2.mm(weight).view(B, M, ns, -1)
+                if ctx.needs_input_grad[1]:
+                    g_new = -gx0[..., :3].sum(dim=2)
+                if ctx.needs_input_grad[2]:
+                    g_feats = torch.zeros_like(feats_pm)
+                    gf = gx0[..., 3:].contiguous()
+                    pointnet2.group_rows_grad(B, feats_pm.shape[1], feats_pm.shape[2], M * ns, gf, idx, g_feats)
+        return None, g_new, g_feats, None, gw
+
+
 # ---- unique-token ("ragged") execution of a PDA scale (csrc/ragged.hip) --------------------------------------------
 # RAGGED_TOKENS: run the encoder of a PDA scale on the distinct (centre, neighbour) tokens only.  RAGGED_MAX_FRACTION:
 # use it when the distinct tokens are at most this share of B*M*nsample (above it the bookkeeping costs more than it saves).

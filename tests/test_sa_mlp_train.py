@@ -1,0 +1,101 @@
+"""-m gpu: training form of the vanilla-SA group MLP on this repo's f32 MFMA kernels (csrc/sa_mlp.hip lin_cols_kernel:
+`pda_linear_cols`, `pda_sa_gather_linear`) against a plain PyTorch fp32 reference of the same op
+(pointnet2_modules.py:1657-1662: Conv2d 1x1 over grouped rows; pointnet2_utils.py:671-704: QueryAndGroup).
+Tolerance: both sides are fp32 with different summation orders (k-ordered fmaf chain vs the library's tiles): 2e-5 of
+the output scale forward, 1e-4 of the gradient scale backward."""
+import os
+import sys
+
+import pytest
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from detweights import fill_deterministic  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("T,K,N", [(1000, 256, 256), (4099, 256, 512), (257, 512, 512), (300, 512, 1024), (64, 256, 128)])
+def test_linear_cols_forward_backward(T, K, N):
+    from pdanet_amd import pointnet2_utils as pu
+    g = torch.Generator("cuda").manual_seed(T + K)
+    x = torch.randn(T, K, device="cuda", generator=g, requires_grad=True)
+    w = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).requires_grad_(True)
+    assert pu.LinearColsMFMA.supported(x, w)
+    y = pu.LinearColsMFMA.apply(x, w)
+    ref = torch.nn.functional.linear(x.double(), w.double())
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    go = torch.randn(T, N, device="cuda", generator=g)
+    gx, gw = torch.autograd.grad(y, (x, w), go)
+    rx, rw = torch.autograd.grad(ref, (x, w), go.double())
+    assert (gx.double() - rx).abs().max().item() <= 1e-4 * rx.abs().max().item()
+    assert (gw.double() - rw).abs().max().item() <= 1e-4 * rw.abs().max().item()
+
+
+@pytest.mark.parametrize("M,ns,n_out", [(100, 16, 256), (257, 32, 256), (33, 64, 128)])
+def test_gather_linear_equals_group_then_linear(M, ns, n_out):
+    from pdanet_amd import pointnet2_utils as pu, synth
+    B, N, C = 2, 2048, 256
+    xyz = torch.from_numpy(synth.batch_xyz(B, N, config_id=3)).cuda()
+    g = torch.Generator("cuda").manual_seed(M)
+    new_xyz = (xyz[:, :M] + 0.1 * torch.randn(B, M, 3, device="cuda", generator=g)).contiguous().requires_grad_(True)
+    feats = torch.randn(B, N, C, device="cuda", generator=g, requires_grad=True)
+    w = (torch.randn(n_out, 3 + C, device="cuda", generator=g) / 16).requires_grad_(True)
+    idx = pu.ball_query(6.0, ns, xyz, new_xyz.detach())
+    assert pu.SaGatherLinear.supported(xyz, feats, w)
+    y = pu.SaGatherLinear.apply(xyz, new_xyz, feats, idx, w)
+    x0 = torch.cat([pu.group_rows(xyz, idx) - new_xyz.unsqueeze(2), pu.group_rows(feats, idx)], dim=-1)
+    ref = torch.nn.functional.linear(x0.double(), w.double())
+    assert y.shape == (B, M, ns, n_out)
+    assert (y.double() - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    go = torch.randn_like(y)
+    got = torch.autograd.grad(y, (new_xyz, feats, w), go)
+    exp = torch.autograd.grad(ref, (new_xyz, feats, w), go.double())
+    for a, b, name in zip(got, exp, ("new_xyz", "feats", "weight")):
+        assert (a.double() - b).abs().max().item() <= 2e-4 * max(1e-6, b.abs().max().item()), name
+
+
+def _layer5():
+    from pdanet_amd.pointnet2_modules import PointnetSAModuleMSG_WithSampling
+    layer = PointnetSAModuleMSG_WithSampling(
+        npoint_list=[256], sample_range_list=[-1], sample_type_list=["D-FPS"], radii=[4.8, 8.4], nsamples=[16, 32],
+        mlps=[[256, 256, 256, 512], [256, 256, 512, 512]], use_xyz=True, dilated_group=False, aggregation_mlp=[512],
+        confidence_mlp=None, num_class=5)
+    return fill_deterministic(layer).cuda().train()
+
+
+def test_sa_layer_training_mfma_path_equals_library_path():
+    """ONCE layer 5 in small, train-mode BatchNorm: the MFMA training path (gather-fused first contraction, own forward and
+    input-gradient GEMMs) against the op-by-op path on library GEMMs -- outputs, input gradients, every parameter gradient,
+    running statistics."""
+    from pdanet_amd import pointnet2_utils as pu, synth
+    xyz = torch.from_numpy(synth.batch_xyz(2, 1024, config_id=4)).cuda()
+    feats0 = torch.randn(2, 256, 1024, device="cuda", generator=torch.Generator("cuda").manual_seed(9))
+    res = {}
+    used = []
+    try:
+        for flag in (True, False):
+            pu.SA_MFMA_TRAIN = flag
+            pu.SA_MFMA_EVENTS = used if flag else None
+            layer = _layer5()
+            feats = feats0.clone().requires_grad_(True)
+            ctr = (xyz[:, :256] + 0.05).contiguous().requires_grad_(True)
+            _, nf, _, _ = layer(xyz, feats, None, ctr_xyz=ctr)
+            nf.pow(2).mean().backward()
+            res[flag] = (nf.detach(), feats.grad.clone(), ctr.grad.clone(),
+                         {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in layer.state_dict().items() if "running" in k})
+    finally:
+        pu.SA_MFMA_TRAIN, pu.SA_MFMA_EVENTS = True, None
+    torch.cuda.synchronize()
+    assert len(used) >= 2 * 5, "the MFMA kernels did not run: %d launches" % len(used)    # 3 forward + 2 input-gradient per scale
+    a, b = res[True], res[False]
+    assert (a[0] - b[0]).abs().max().item() <= 2e-4 * max(1.0, b[0].abs().max().item())
+    for i in (1, 2):
+        assert (a[i] - b[i]).abs().max().item() <= 2e-3 * b[i].abs().max().item() + 1e-8
+    gmax = max(float(v.abs().max()) for v in b[3].values())
+    assert set(a[3]) == set(b[3])
+    for k in b[3]:
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-2 * float(b[3][k].abs().max()) + 1e-3 * gmax, k
+    for k in b[4]:
+        assert torch.allclose(a[4][k], b[4][k], rtol=1e-4, atol=1e-5), k

@@ -5,6 +5,7 @@
   ball_query   layer-0 ball query 16384 x 16384, 2 radii    -> traffic["pda::ball_query 16384x16384 r2 b2"]
   wgrad        dW(512x512) over 131072 tokens               -> traffic[...], mfma_util["pda::wgrad_kernel ..."]
   sa_mlp       fused SA scale 259->256->512->512, ns 64     -> mfma_util["pda::sa_mlp_kernel ..."]
+  lin_cols     training-form contraction 512->512, 131072 tokens -> mfma_util["pda::lin_cols_kernel ..."]
 Inputs are the bench's (synth scene config_id 2, distribution L)."""
 import sys
 
@@ -42,6 +43,13 @@ elif target == "sa_mlp":
     with torch.no_grad():
         for _ in range(reps):
             layer(pts, feats, None, ctr_xyz=pts[:, :1024].contiguous())
+elif target == "lin_cols":
+    # training form of the group MLP: ONCE layer 5, scale 3, layer 3 forward (131072 tokens, 512 -> 512)
+    t, k, n = 131072, 512, 512
+    x, w, y = torch.randn(t, k, device=dev), torch.randn(n, k, device=dev), torch.empty(t, n, device=dev)
+    wf = ext.linear_cols_pack(w, n, k)
+    for _ in range(reps):
+        ext.linear_cols(x, wf, y, t, k, n)
 else:
     raise SystemExit("unknown target " + target)
 torch.cuda.synchronize()
