@@ -148,16 +148,22 @@ __device__ __forceinline__ void gemm_chunk_rt(f32x16 (&acc)[CH], const HinT& hin
     for (int r = 0; r < CH; ++r)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
-    float4 cur[CH], nxt[CH];
+    // weight fragments of k-chunks tq+1 and tq+2 are in flight while chunk tq feeds the MFMAs (one wave per SIMD:
+    // nothing else hides the L2 latency of the weight stream)
+    float4 buf[3][CH];
     const float* base = wf + ((size_t)rb0 * 64 + lane) * 4;
     const size_t step = (size_t)R * 64 * 4;
 #pragma unroll
-    for (int r = 0; r < CH; ++r) cur[r] = *reinterpret_cast<const float4*>(base + (size_t)r * 256);
+    for (int r = 0; r < CH; ++r) buf[0][r] = *reinterpret_cast<const float4*>(base + (size_t)r * 256);
+    if (TQ > 1) {
+#pragma unroll
+        for (int r = 0; r < CH; ++r) buf[1][r] = *reinterpret_cast<const float4*>(base + step + (size_t)r * 256);
+    }
 #pragma unroll
     for (int tq = 0; tq < TQ; ++tq) {
-        if (tq + 1 < TQ) {
+        if (tq + 2 < TQ) {
 #pragma unroll
-            for (int r = 0; r < CH; ++r) nxt[r] = *reinterpret_cast<const float4*>(base + (size_t)(tq + 1) * step + (size_t)r * 256);
+            for (int r = 0; r < CH; ++r) buf[(tq + 2) % 3][r] = *reinterpret_cast<const float4*>(base + (size_t)(tq + 2) * step + (size_t)r * 256);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -165,14 +171,12 @@ __device__ __forceinline__ void gemm_chunk_rt(f32x16 (&acc)[CH], const HinT& hin
             const float b = hin(tq * 4 + e);
 #pragma unroll
             for (int r = 0; r < CH; ++r) {
-                const float4 a4 = cur[r];
+                const float4 a4 = buf[tq % 3][r];
                 const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int r = 0; r < CH; ++r) cur[r] = nxt[r];
     }
 }
 

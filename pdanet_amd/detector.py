@@ -57,6 +57,11 @@ class IASSD(nn.Module):
         if self._graphed is None or self._graphed[0] != key:
             fn = _HeadLoss(self.point_head, bd['batch_size'], [isinstance(p, torch.Tensor) for p in sa], len(bd['encoder_coords']))
             sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+            # the warm-up iterations run on a side stream: AccumulateGrad nodes created there trigger a (harmless)
+            # stream-mismatch warning on the first real backward; silence it for the capture only
+            warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if warn is not None:
+                warn(False)
             graphed = torch.cuda.make_graphed_callables(fn, sample, allow_unused_input=True)
             self._graphed = (key, graphed, fn)
         _, graphed, fn = self._graphed
