@@ -27,7 +27,7 @@ constexpr int BQC_MAX_CELLS = 1 << 17;  // cells per scene
 constexpr int BQC_WAVES = 4;
 
 struct BqcGrid {        // per scene, written by bqc_grid_kernel
-    float ox, oy, oz, inv_g;
+    float ox, oy, oz, inv_gx, inv_gy, inv_gz;
     int nx, ny, nz, ncell;
 };
 
@@ -37,7 +37,8 @@ __device__ __forceinline__ int bqc_coord(float v, float o, float inv_g, int dim)
 }
 
 // one workgroup per scene: bounding box of the points -> grid
-__global__ __launch_bounds__(1024) void bqc_grid_kernel(const float* __restrict__ xyz_all, BqcGrid* __restrict__ grids, int n, float g_min) {
+__global__ __launch_bounds__(1024) void bqc_grid_kernel(const float* __restrict__ xyz_all, BqcGrid* __restrict__ grids, int n, float g_min,
+                                                        int max_cells) {
     __shared__ float red[16 * 6];
     const float* xyz = xyz_all + (size_t)blockIdx.x * n * 3;
     const float INF = __builtin_inff();
@@ -59,23 +60,31 @@ __global__ __launch_bounds__(1024) void bqc_grid_kernel(const float* __restrict_
         for (int q = 0; q < 16; ++q) { mn = fminf(mn, red[q * 6 + a]); mx = fmaxf(mx, red[q * 6 + 3 + a]); }
         lo[a] = mn; hi[a] = mx;
     }
-    float g = g_min;
-    int nx, ny, nz;
-    for (;;) {   // grow the cells until the grid fits the table (bounded: the edge grows 26 % per pass)
-        nx = (int)floorf((hi[0] - lo[0]) / g) + 1; ny = (int)floorf((hi[1] - lo[1]) / g) + 1; nz = (int)floorf((hi[2] - lo[2]) / g) + 1;
-        if ((int64_t)nx * ny * nz <= BQC_MAX_CELLS && nx < 32768 && ny < 32768 && nz < 32768) break;
-        g *= 1.26f;
+    // Cell edges >= g_min per axis, at most `max_cells` cells (the table is scanned by one workgroup per scene, so a small
+    // table is worth more than thin cells).  LiDAR scenes are flat: the vertical axis is coarsened first (doubling its
+    // edge costs a few extra candidates per centre, the horizontal edges cost their square), then all three grow.
+    float g[3] = {g_min, g_min, g_min};
+    int nc[3];
+    const float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
+    const int thin = (ext[2] <= ext[0] && ext[2] <= ext[1]) ? 2 : (ext[1] <= ext[0] ? 1 : 0);
+    for (;;) {   // bounded: every pass grows an edge by >= 26 %
+#pragma unroll
+        for (int a = 0; a < 3; ++a) nc[a] = (int)fminf(floorf(ext[a] / g[a]), 32766.f) + 1;
+        if ((int64_t)nc[0] * nc[1] * nc[2] <= max_cells) break;
+        if (nc[thin] > 1) g[thin] *= 2.0f;
+        else { g[0] *= 1.26f; g[1] *= 1.26f; g[2] *= 1.26f; }
     }
     BqcGrid gr;
-    gr.ox = lo[0]; gr.oy = lo[1]; gr.oz = lo[2]; gr.inv_g = 1.0f / g;
-    gr.nx = nx; gr.ny = ny; gr.nz = nz; gr.ncell = nx * ny * nz;
+    gr.ox = lo[0]; gr.oy = lo[1]; gr.oz = lo[2];
+    gr.inv_gx = 1.0f / g[0]; gr.inv_gy = 1.0f / g[1]; gr.inv_gz = 1.0f / g[2];
+    gr.nx = nc[0]; gr.ny = nc[1]; gr.nz = nc[2]; gr.ncell = nc[0] * nc[1] * nc[2];
     grids[blockIdx.x] = gr;
 }
 
 __device__ __forceinline__ int bqc_cell_of_point(const BqcGrid& gr, float x, float y, float z) {
-    const int ix = min(max(bqc_coord(x, gr.ox, gr.inv_g, gr.nx), 0), gr.nx - 1);
-    const int iy = min(max(bqc_coord(y, gr.oy, gr.inv_g, gr.ny), 0), gr.ny - 1);
-    const int iz = min(max(bqc_coord(z, gr.oz, gr.inv_g, gr.nz), 0), gr.nz - 1);
+    const int ix = min(max(bqc_coord(x, gr.ox, gr.inv_gx, gr.nx), 0), gr.nx - 1);
+    const int iy = min(max(bqc_coord(y, gr.oy, gr.inv_gy, gr.ny), 0), gr.ny - 1);
+    const int iz = min(max(bqc_coord(z, gr.oz, gr.inv_gz, gr.nz), 0), gr.nz - 1);
     return (iz * gr.ny + iy) * gr.nx + ix;   // x fastest: the 3 x-neighbours of a cell are contiguous
 }
 
@@ -100,26 +109,26 @@ __device__ __forceinline__ int bqc_wave_slot(int32_t* table, int cell, bool acti
 
 // counts[scene][cell] += 1 (counts zero-filled by the launcher)
 __global__ __launch_bounds__(256) void bqc_count_kernel(const float* __restrict__ xyz_all, const BqcGrid* __restrict__ grids,
-                                                        int32_t* __restrict__ counts, int n) {
+                                                        int32_t* __restrict__ counts, int n, int tstride) {
     const int s = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     const bool active = k < n;
     const BqcGrid gr = grids[s];
     const float* p = xyz_all + ((size_t)s * n + (active ? k : 0)) * 3;
-    bqc_wave_slot(counts + (size_t)s * (BQC_MAX_CELLS + 1), bqc_cell_of_point(gr, p[0], p[1], p[2]), active);
+    bqc_wave_slot(counts + (size_t)s * tstride, bqc_cell_of_point(gr, p[0], p[1], p[2]), active);
 }
 
 // one workgroup per scene: exclusive scan of the cell counts in place -> starts; cursor = copy of the starts.
 // Tiles of 16384 cells go through LDS (coalesced both ways); thread t scans its 16 consecutive cells of the tile.
 __global__ __launch_bounds__(1024) void bqc_scan_kernel(const BqcGrid* __restrict__ grids, int32_t* __restrict__ counts,
-                                                        int32_t* __restrict__ cursor) {
+                                                        int32_t* __restrict__ cursor, int tstride) {
     constexpr int PER = 16, TILE = 1024 * PER;
     __shared__ int32_t tile[TILE + TILE / 16];     // 16-int rows padded by one: conflict-free row scans
     __shared__ int32_t part[1024];
     const int s = blockIdx.x, t = threadIdx.x;
     const int ncell = grids[s].ncell;
-    int32_t* c = counts + (size_t)s * (BQC_MAX_CELLS + 1);
-    int32_t* cur = cursor + (size_t)s * (BQC_MAX_CELLS + 1);
+    int32_t* c = counts + (size_t)s * tstride;
+    int32_t* cur = cursor + (size_t)s * tstride;
     int32_t carry = 0;
     for (int base = 0; base < ncell; base += TILE) {
         for (int i = t; i < TILE; i += 1024) tile[i + i / 16] = base + i < ncell ? c[base + i] : 0;
@@ -150,14 +159,15 @@ __global__ __launch_bounds__(1024) void bqc_scan_kernel(const BqcGrid* __restric
 
 // records[scene][cursor[cell]++] = {x, y, z, index}
 __global__ __launch_bounds__(256) void bqc_scatter_kernel(const float* __restrict__ xyz_all, const BqcGrid* __restrict__ grids,
-                                                          int32_t* __restrict__ cursor, float4* __restrict__ records, int n) {
+                                                          int32_t* __restrict__ cursor, float4* __restrict__ records, int n,
+                                                          int tstride) {
     const int s = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     const bool active = k < n;
     const BqcGrid gr = grids[s];
     const float* p = xyz_all + ((size_t)s * n + (active ? k : 0)) * 3;
     const float x = p[0], y = p[1], z = p[2];
-    const int slot = bqc_wave_slot(cursor + (size_t)s * (BQC_MAX_CELLS + 1), bqc_cell_of_point(gr, x, y, z), active);
+    const int slot = bqc_wave_slot(cursor + (size_t)s * tstride, bqc_cell_of_point(gr, x, y, z), active);
     if (active) records[(size_t)s * n + slot] = make_float4(x, y, z, __int_as_float(k));
 }
 
@@ -170,7 +180,7 @@ struct BqcParams {
     int32_t* idx[BQC_MAX_NR];
     float r2[BQC_MAX_NR];
     int ns[BQC_MAX_NR];
-    int n, m;
+    int n, m, tstride;
 };
 
 // number of set bits of `mask` below my lane
@@ -232,9 +242,9 @@ __global__ __launch_bounds__(BQC_WAVES * 64) void ball_query_cells_kernel(const 
     const BqcGrid gr = p.grids[s];
     const float* q = p.new_xyz + ((size_t)s * p.m + c) * 3;
     const float cx = q[0], cy = q[1], cz = q[2];
-    const int32_t* starts = p.starts + (size_t)s * (BQC_MAX_CELLS + 1);
+    const int32_t* starts = p.starts + (size_t)s * p.tstride;
     const float4* rec = p.records + (size_t)s * p.n;
-    const int ix = bqc_coord(cx, gr.ox, gr.inv_g, gr.nx), iy = bqc_coord(cy, gr.oy, gr.inv_g, gr.ny), iz = bqc_coord(cz, gr.oz, gr.inv_g, gr.nz);
+    const int ix = bqc_coord(cx, gr.ox, gr.inv_gx, gr.nx), iy = bqc_coord(cy, gr.oy, gr.inv_gy, gr.ny), iz = bqc_coord(cz, gr.oz, gr.inv_gz, gr.nz);
     const int x0 = max(ix - 1, 0), x1 = min(ix + 1, gr.nx - 1);
     int len[NR];
     bool over = false;
@@ -334,16 +344,20 @@ PDA_API int pda_ball_query_cells(const float* new_xyz, const float* xyz, int32_t
     int32_t* counts = (int32_t*)(base + grids_b);
     int32_t* cursor = (int32_t*)(base + grids_b + table_b);
     float4* records = (float4*)(base + grids_b + 2 * table_b);
-    if (hipMemsetAsync(counts, 0, (size_t)table_b, st) != hipSuccess) {
+    // table size: about one cell per point, a power of two in [4096, BQC_MAX_CELLS]
+    int max_cells = 4096;
+    while (max_cells < n && max_cells < BQC_MAX_CELLS) max_cells *= 2;
+    const int tstride = max_cells + 1;
+    if (hipMemsetAsync(counts, 0, (size_t)b * tstride * 4, st) != hipSuccess) {
         set_error("pda_ball_query_cells: hipMemsetAsync failed");
         return PDA_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(bqc_grid_kernel, dim3(b), dim3(1024), 0, st, xyz, grids, n, rmax * 1.01f);
-    hipLaunchKernelGGL(bqc_count_kernel, dim3(divup(n, 256), b), dim3(256), 0, st, xyz, grids, counts, n);
-    hipLaunchKernelGGL(bqc_scan_kernel, dim3(b), dim3(1024), 0, st, grids, counts, cursor);
-    hipLaunchKernelGGL(bqc_scatter_kernel, dim3(divup(n, 256), b), dim3(256), 0, st, xyz, grids, cursor, records, n);
+    hipLaunchKernelGGL(bqc_grid_kernel, dim3(b), dim3(1024), 0, st, xyz, grids, n, rmax * 1.01f, max_cells);
+    hipLaunchKernelGGL(bqc_count_kernel, dim3(divup(n, 256), b), dim3(256), 0, st, xyz, grids, counts, n, tstride);
+    hipLaunchKernelGGL(bqc_scan_kernel, dim3(b), dim3(1024), 0, st, grids, counts, cursor, tstride);
+    hipLaunchKernelGGL(bqc_scatter_kernel, dim3(divup(n, 256), b), dim3(256), 0, st, xyz, grids, cursor, records, n, tstride);
     BqcParams p{};
-    p.new_xyz = new_xyz; p.xyz = xyz; p.grids = grids; p.starts = counts; p.records = records; p.n = n; p.m = m;
+    p.new_xyz = new_xyz; p.xyz = xyz; p.grids = grids; p.starts = counts; p.records = records; p.n = n; p.m = m; p.tstride = tstride;
     for (int i = 0; i < nr; ++i) { p.idx[i] = idx[i]; p.r2[i] = radii[i] * radii[i]; p.ns[i] = nsamples[i]; }
     const dim3 grid(divup(m, BQC_WAVES), b), block(BQC_WAVES * 64);
     if (nr == 1) hipLaunchKernelGGL(ball_query_cells_kernel<1>, grid, block, 0, st, p);
