@@ -247,7 +247,6 @@ __global__ __launch_bounds__(BQC_WAVES * 64) void ball_query_cells_kernel(const 
     const int ix = bqc_coord(cx, gr.ox, gr.inv_gx, gr.nx), iy = bqc_coord(cy, gr.oy, gr.inv_gy, gr.ny), iz = bqc_coord(cz, gr.oz, gr.inv_gz, gr.nz);
     const int x0 = max(ix - 1, 0), x1 = min(ix + 1, gr.nx - 1);
     int len[NR];
-    bool over = false;
 #pragma unroll
     for (int i = 0; i < NR; ++i) len[i] = 0;
     if (x0 <= x1) {
@@ -271,7 +270,6 @@ __global__ __launch_bounds__(BQC_WAVES * 64) void ball_query_cells_kernel(const 
                         const int pos = len[i] + lane_prefix(mk);
                         if (hit && pos < BQC_LCAP) lists[w][i][pos] = __float_as_int(r.w);
                         len[i] += __builtin_popcountll(mk);
-                        over |= len[i] > BQC_LCAP;
                     }
                 }
             }
@@ -306,7 +304,6 @@ __global__ __launch_bounds__(BQC_WAVES * 64) void ball_query_cells_kernel(const 
         // the rest of the row repeats the first hit (ball_query_gpu.cu:35-39)
         for (int j = k + lane; j < ns; j += 64) row[j] = first;
     }
-    (void)over;
 }
 
 }  // namespace pda

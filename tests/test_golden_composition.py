@@ -286,3 +286,34 @@ def test_resident_input_prefetch_gives_identical_results():
     for o in outs[1:]:
         for a, b in zip(outs[0], o):
             assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_backbone_prefetch_starts_the_next_forward_early_and_changes_nothing():
+    """backbone.prefetch(points): sampling, layer-1 ball queries and unique-token plans of the NEXT forward, started on the
+    side stream ahead of time.  Same results as a plain forward; a stash made for another tensor is ignored."""
+    import torch
+    from pdanet_amd import synth
+    from pdanet_amd.backbone import build_backbone
+    torch.manual_seed(1)
+    model, _ = build_backbone("once_pda_ssd.yaml")
+    model = model.cuda().eval()
+    pts = torch.from_numpy(synth.batch_points(2, 4096, config_id=2)).cuda()
+    other = torch.from_numpy(synth.batch_points(2, 4096, config_id=7)).cuda()
+    torch.cuda.synchronize()
+
+    def run(p):
+        with torch.no_grad():
+            bd = model({'batch_size': 2, 'points': p, 'inputs_resident': True})
+        return bd['centers'].clone(), bd['centers_features'].clone(), bd['encoder_xyz'][2].clone()
+    ref, ref_other = run(pts), run(other)
+    model.prefetch(pts, 2)
+    assert model._prefetched is not None
+    got = run(pts)                               # consumes the stash
+    assert model._prefetched is None
+    model.prefetch(pts, 2)
+    got_other = run(other)                       # stash belongs to another batch: dropped, computed afresh
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    for a, b in zip(ref_other, got_other):
+        assert torch.equal(a, b)
