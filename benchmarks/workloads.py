@@ -519,7 +519,8 @@ class DetectorTrainWorkload(TrainStepWorkload):
         model, self.cfg = detector.build_detector(cfg)
         self.model = model.to(device).train()
         self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
-        # head + losses replayed as hipGraphs (detector.IASSD.graph_head); DDP runs keep the eager head
+        # head + losses replayed as hipGraphs (detector.IASSD.graph_head); DDP runs keep the eager head (a two-rank
+        # rehearsal with the graphed head under DDP crashed in capture: not pursued without multi-GPU hardware)
         self.model.graph_head = world == 1 and os.environ.get("PDA_GRAPH_HEAD", "1") != "0"
         self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
