@@ -130,6 +130,16 @@ int pda_add_max_pool_bf16(const float *a, const uint16_t *b, float *out, uint8_t
 int pda_max_pool_scatter_bf16(const float *grad_out, const uint8_t *arg, float *grad_x, uint16_t *grad_x_bf16,
                               int64_t groups, int seq, int d, pda_stream_t stream);
 
+/* Multiplicity-weighted training-mode BatchNorm + ReLU (rows stand for row_weight[r] identical rows of a dense tensor of
+ * `count` rows): same results as pda_bn_relu_fwd/bwd on the dense tensor, with grad_y / grad_x the SUMS over the copies. */
+int pda_bn_relu_fwd_weighted(const float *x, const float *gamma, const float *beta, float *running_mean,
+                             float *running_var, float *y, float *mean_invstd, void *scratch, int64_t rows, int c,
+                             float eps, float momentum, const float *row_weight, int64_t count, pda_stream_t stream);
+int pda_bn_relu_bwd_weighted(const float *x, const float *grad_y, const float *gamma, const float *beta,
+                             const float *mean_invstd, float *grad_x, float *grad_gamma, float *grad_beta,
+                             void *scratch, int64_t rows, int c, const float *row_weight, int64_t count,
+                             pda_stream_t stream);
+
 /* ---- unique-token ("ragged") execution of a PDA scale (MI355X extension; csrc/ragged.hip) -----------------
  * ball_query pads a short neighbour list with repeats of its first entry (ball_query_gpu.cu:35-41), and the PDA
  * layer runs its transformer encoder over all nsample tokens of every centre (pointnet2_modules.py:924-931).  A
@@ -138,22 +148,27 @@ int pda_max_pool_scatter_bf16(const float *grad_out, const uint8_t *arg, float *
  * (key 0 of a group enters the softmax with weight nsample - cnt + 1; the max over a group ignores repeats; a
  * compact token receives the summed gradient of its copies).
  * pda_ragged_plan: idx (groups, nsample) -> cnt (groups), off (groups + 1; off[groups] = U = number of distinct
- *   tokens), rowmap (>= U; compact row -> dense row g * nsample + s).  No synchronisation: the caller reads U.
+ *   tokens), rowmap (>= U; compact row -> dense row g * nsample + s), row_weight (>= U, optional: the multiplicity of
+ *   each compact token, nsample - cnt + 1 for slot 0 and 1 otherwise).  No synchronisation: the caller reads U.
+ * rppe_compact != 0: the position-encoding rows (and their gradient) are compact (U, C) as well -- the position MLP
+ *   ran on the distinct tokens with pda_bn_relu_{fwd,bwd}_weighted (statistics of the dense tensor from weighted sums;
+ *   a compact row's gradient is the sum over its copies).
  * pda_assemble_tokens_ragged(_grad): pda_assemble_tokens writing / reading compact rows (out (U, 4C)); the grid
  *   covers max_tokens >= U rows and reads U on the device.  The gradient entry writes the DENSE grad_rppe /
  *   grad_dscale (zero at the repeat slots) and grad_glob, and ADDS into grad_feats (zero-filled by the caller).
  * pda_add_max_pool_ragged / pda_max_pool_scatter_ragged: the add + max-pool tail on compact rows; arg = slot.
  * pda_group_attention_ragged_fwd/bwd (include/pda_pointnet2.h layout with compact rows): qkv (U, 3, H, hd),
  *   out / grad_out (U, H * hd), lse (groups, H, seq). */
-int pda_ragged_plan(const int32_t *idx, int32_t *cnt, int32_t *off, int32_t *rowmap, int64_t groups, int nsample,
-                    pda_stream_t stream);
+int pda_ragged_plan(const int32_t *idx, int32_t *cnt, int32_t *off, int32_t *rowmap, float *row_weight, int64_t groups,
+                    int nsample, pda_stream_t stream);
 int pda_assemble_tokens_ragged(const float *rppe, const float *dscale, const float *feats, const int32_t *idx,
                                const float *glob, const int32_t *rowmap, const int32_t *off, float *out,
-                               int64_t max_tokens, int b, int n, int m, int nsample, int c, pda_stream_t stream);
+                               int64_t max_tokens, int b, int n, int m, int nsample, int c, int rppe_compact,
+                               pda_stream_t stream);
 int pda_assemble_tokens_ragged_grad(const float *grad_out, const float *dscale, const float *feats,
                                     const int32_t *idx, const int32_t *cnt, const int32_t *off, float *grad_rppe,
                                     float *grad_dscale, float *grad_feats, float *grad_glob, int b, int n, int m,
-                                    int nsample, int c, pda_stream_t stream);
+                                    int nsample, int c, int rppe_compact, pda_stream_t stream);
 int pda_add_max_pool_ragged(const float *a, const float *b, const int32_t *cnt, const int32_t *off, float *out,
                             uint8_t *arg, int64_t groups, int d, pda_stream_t stream);
 int pda_max_pool_scatter_ragged(const float *grad_out, const uint8_t *arg, const int32_t *rowmap,

@@ -19,6 +19,11 @@ struct BnShape {
     int64_t rows;
     int c, cg, rpb;  // cg = C/4 thread columns; rpb = rows per block step = 256 / cg (>= 1)
     int ns;          // pooled forms: rows per group (the max-pool runs over ns consecutive rows)
+    // Multiplicity-weighted form (unique-token execution, csrc/ragged.hip): row r stands for roww[r] identical rows of
+    // the dense tensor; the statistics are those of the dense tensor (count = its number of rows) and a row's gradient is
+    // the SUM over its copies.  roww == nullptr: every weight is 1 and count == rows.
+    const float* roww;
+    int64_t count;
 };
 
 // Pooled backward: the incoming gradient is that of out[g][c] = max over the ns rows of group g of y; it reaches row
@@ -74,8 +79,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TX* __restrict__ x
         for (int64_t r = (int64_t)blockIdx.x * s.rpb + r0; r < s.rows; r += (int64_t)gridDim.x * s.rpb) {
             const float4 v = load4(x + r * s.c + 4 * col);
             if (!BWD) {
-                a[0] += v.x; a[1] += v.y; a[2] += v.z; a[3] += v.w;
-                b[0] += (double)v.x * v.x; b[1] += (double)v.y * v.y; b[2] += (double)v.z * v.z; b[3] += (double)v.w * v.w;
+                const double w = s.roww ? (double)s.roww[r] : 1.0;
+                a[0] += w * v.x; a[1] += w * v.y; a[2] += w * v.z; a[3] += w * v.w;
+                b[0] += w * ((double)v.x * v.x); b[1] += w * ((double)v.y * v.y); b[2] += w * ((double)v.z * v.z); b[3] += w * ((double)v.w * v.w);
             } else {
                 float4 d;
                 if constexpr (POOL) d = pooled_grad(reinterpret_cast<const float*>(dy), arg, r, col, s);
@@ -184,11 +190,12 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
             if constexpr (POOL) d = pooled_grad(reinterpret_cast<const float*>(dy), arg, r, col, s);
             else d = load4(dy + r * s.c + 4 * col);
             const float dv[4] = {d.x, d.y, d.z, d.w};
+            const float w = s.roww ? s.roww[r] : 1.f;      // the copies of a row share the mean terms, the incoming gradient is their sum
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const float xh = (xv[k] - muv[k]) * isv[k];
                 const float dyh = (xh * gv[k] + bv[k] > 0.f) ? dv[k] : 0.f;
-                o[k] = gv[k] * isv[k] * (dyh - m1v[k] - xh * m2v[k]);
+                o[k] = gv[k] * isv[k] * (dyh - w * (m1v[k] + xh * m2v[k]));
             }
         }
         store4(out + r * s.c + 4 * col, make_float4(o[0], o[1], o[2], o[3]));
@@ -228,6 +235,7 @@ static int bn_shape(int64_t rows, int c, BnShape& s, const char* what) {
     PDA_REQUIRE(rows >= 1, "%s: rows = %lld", what, (long long)rows);
     PDA_REQUIRE(c >= 4 && c <= 1024 && (c & (c - 1)) == 0, "%s: C = %d is not a power of two in [4, 1024]", what, c);
     s.rows = rows; s.c = c; s.cg = c / 4; s.rpb = 256 / s.cg; s.ns = 1;
+    s.roww = nullptr; s.count = rows;
     return PDA_OK;
 }
 
@@ -250,9 +258,10 @@ template <typename T> static bool bn_aligned(const T* p) { return ((uintptr_t)p 
 template <typename TX, typename TY>
 static int launch_bn_relu_fwd(const TX* x, const float* gamma, const float* beta, float* running_mean, float* running_var, TY* y,
                               float* mean_invstd, void* scratch, int64_t rows, int c, float eps, float momentum, hipStream_t st,
-                              const char* what) {
+                              const char* what, const float* roww = nullptr, int64_t count = 0) {
     BnShape s;
     if (int rc = bn_shape(rows, c, s, what)) return rc;
+    if (roww) { PDA_REQUIRE(count >= rows, "%s: count = %lld < rows", what, (long long)count); s.roww = roww; s.count = count; }
     PDA_REQUIRE(x && gamma && beta && y && mean_invstd && scratch, "%s: null pointer", what);
     PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running_mean/var must come together", what);
     PDA_REQUIRE(bn_aligned(x) && bn_aligned(y) && (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
@@ -260,7 +269,7 @@ static int launch_bn_relu_fwd(const TX* x, const float* gamma, const float* beta
     const int grid = bn_grid(s);
     hipLaunchKernelGGL((bn_reduce_kernel<false, TX, float>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
                        (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, eps, momentum,
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, s.count, eps, momentum,
                        mean_invstd, running_mean, running_var);
     hipLaunchKernelGGL((bn_apply_kernel<false, TX, float, TY>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, mean_invstd, gamma, beta,
                        (const float*)nullptr, y, s);
@@ -269,9 +278,11 @@ static int launch_bn_relu_fwd(const TX* x, const float* gamma, const float* beta
 
 template <typename TX, typename TD>
 static int launch_bn_relu_bwd(const TX* x, const TD* grad_y, const float* gamma, const float* beta, const float* mean_invstd, TX* grad_x,
-                              float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c, hipStream_t st, const char* what) {
+                              float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c, hipStream_t st, const char* what,
+                              const float* roww = nullptr, int64_t count = 0) {
     BnShape s;
     if (int rc = bn_shape(rows, c, s, what)) return rc;
+    if (roww) { PDA_REQUIRE(count >= rows, "%s: count = %lld < rows", what, (long long)count); s.roww = roww; s.count = count; }
     PDA_REQUIRE(x && grad_y && gamma && beta && mean_invstd && grad_x && grad_gamma && grad_beta && scratch, "%s: null pointer", what);
     PDA_REQUIRE(bn_aligned(x) && bn_aligned(grad_y) && bn_aligned(grad_x) && (((uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0,
                 "%s: pointers must be 16-byte aligned (8 for bf16 tensors)", what);
@@ -279,7 +290,7 @@ static int launch_bn_relu_bwd(const TX* x, const TD* grad_y, const float* gamma,
     // the per-channel means of the second pass live behind the partials in the scratch buffer
     float* sums = reinterpret_cast<float*>(reinterpret_cast<double*>(scratch) + (size_t)BN_BLOCKS * 2 * c);
     hipLaunchKernelGGL((bn_reduce_kernel<true, TX, TD>), dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, (double*)scratch, s);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, rows, grad_gamma, grad_beta,
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, s.count, grad_gamma, grad_beta,
                        sums);
     hipLaunchKernelGGL((bn_apply_kernel<true, TX, TD, TX>), dim3(grid), dim3(256), 0, st, x, grad_y, mean_invstd, gamma, beta, sums, grad_x, s);
     return check_launch(what);
@@ -343,6 +354,22 @@ PDA_API int pda_bn_relu_bwd(const float* x, const float* grad_y, const float* ga
                             pda_stream_t stream) {
     return pda::launch_bn_relu_bwd<float, float>(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c,
                                                  (hipStream_t)stream, "pda_bn_relu_bwd");
+}
+
+PDA_API int pda_bn_relu_fwd_weighted(const float* x, const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     float* y, float* mean_invstd, void* scratch, int64_t rows, int c, float eps, float momentum,
+                                     const float* row_weight, int64_t count, pda_stream_t stream) {
+    PDA_REQUIRE(row_weight != nullptr, "pda_bn_relu_fwd_weighted: null pointer");
+    return pda::launch_bn_relu_fwd<float, float>(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum,
+                                                 (hipStream_t)stream, "pda_bn_relu_fwd_weighted", row_weight, count);
+}
+
+PDA_API int pda_bn_relu_bwd_weighted(const float* x, const float* grad_y, const float* gamma, const float* beta, const float* mean_invstd,
+                                     float* grad_x, float* grad_gamma, float* grad_beta, void* scratch, int64_t rows, int c,
+                                     const float* row_weight, int64_t count, pda_stream_t stream) {
+    PDA_REQUIRE(row_weight != nullptr, "pda_bn_relu_bwd_weighted: null pointer");
+    return pda::launch_bn_relu_bwd<float, float>(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c,
+                                                 (hipStream_t)stream, "pda_bn_relu_bwd_weighted", row_weight, count);
 }
 
 PDA_API int pda_bn_relu_fwd_mixed(const void* x, int x_is_bf16, const float* gamma, const float* beta, float* running_mean,

@@ -54,12 +54,18 @@ __global__ __launch_bounds__(1024) void ragged_plan_kernel(const int32_t* __rest
 }
 
 // rowmap[off[g] + s] = g * ns + s for s < cnt[g]: the dense (group, slot) row a compact token came from.
+// roww (optional): the multiplicity of the compact token -- slot 0 stands for itself and the ns - cnt repeats
 __global__ __launch_bounds__(256) void ragged_rowmap_kernel(const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
-                                                            int32_t* __restrict__ rowmap, int64_t total, int ns) {
+                                                            int32_t* __restrict__ rowmap, float* __restrict__ roww, int64_t total,
+                                                            int ns) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (group, slot)
     if (e >= total) return;
     const int g = (int)(e / ns), s = (int)(e % ns);
-    if (s < cnt[g]) rowmap[off[g] + s] = (int32_t)e;
+    const int c = cnt[g];
+    if (s < c) {
+        rowmap[off[g] + s] = (int32_t)e;
+        if (roww) roww[off[g] + s] = s == 0 ? (float)(ns - c + 1) : 1.f;
+    }
 }
 
 // Token assembly (csrc/assemble.hip) writing COMPACT rows: thread = (compact token u, 4-channel column).
@@ -67,7 +73,7 @@ __global__ __launch_bounds__(256) void assemble_ragged_fwd_kernel(const float* _
                                                                   const float* __restrict__ feats, const int* __restrict__ idx,
                                                                   const float* __restrict__ glob, const int32_t* __restrict__ rowmap,
                                                                   const int32_t* __restrict__ off, float* __restrict__ out, int n,
-                                                                  int m, int ns, int c4, int groups) {
+                                                                  int m, int ns, int c4, int groups, int rppe_compact) {
     const int64_t total = (int64_t)off[groups] * c4;             // U is read on the device: the grid covers a host bound
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
@@ -76,7 +82,7 @@ __global__ __launch_bounds__(256) void assemble_ragged_fwd_kernel(const float* _
     const int64_t tok = rowmap[u];
     const int64_t bm = tok / ns;
     const int64_t b = bm / m;
-    const float4 r = reinterpret_cast<const float4*>(rppe)[tok * c4 + c];
+    const float4 r = reinterpret_cast<const float4*>(rppe)[(rppe_compact ? u : tok) * c4 + c];
     const float4 f = reinterpret_cast<const float4*>(feats)[((size_t)b * n + idx[tok]) * c4 + c];
     const float4 g = reinterpret_cast<const float4*>(glob)[bm * c4 + c];
     const float d = dscale[tok];
@@ -96,7 +102,7 @@ __global__ __launch_bounds__(256) void assemble_ragged_bwd_kernel(const float* _
                                                                   const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
                                                                   float* __restrict__ d_rppe, float* __restrict__ d_dscale,
                                                                   float* __restrict__ d_feats, float* __restrict__ d_glob, int n,
-                                                                  int m, int ns, int64_t total) {
+                                                                  int m, int ns, int64_t total, int rppe_compact) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (centre, column)
     const bool live = e < total;
     const int64_t ec = live ? e : total - 1;                     // dead lanes shadow the last element (shuffles stay uniform)
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void assemble_ragged_bwd_kernel(const float* _
         const int64_t tok = tok0 + t;
         if (t >= n_tok) {      // uniform over the c4 lanes of a centre
             if (live) {
-                reinterpret_cast<float4*>(d_rppe)[(size_t)tok * c4 + c] = zero;
+                if (!rppe_compact) reinterpret_cast<float4*>(d_rppe)[(size_t)tok * c4 + c] = zero;
                 if (c == 0) d_dscale[tok] = 0.f;
             }
             continue;
@@ -128,7 +134,7 @@ __global__ __launch_bounds__(256) void assemble_ragged_bwd_kernel(const float* _
         for (int o = c4 >> 1; o >= 1; o >>= 1) part += __shfl_xor(part, o);
         acc_g.x += g_g.x; acc_g.y += g_g.y; acc_g.z += g_g.z; acc_g.w += g_g.w;
         if (live) {
-            reinterpret_cast<float4*>(d_rppe)[(size_t)tok * c4 + c] = g_r;
+            reinterpret_cast<float4*>(d_rppe)[(size_t)(rppe_compact ? u0 + t : tok) * c4 + c] = g_r;
             if (c == 0) d_dscale[tok] = part;
             float* df = d_feats + (((size_t)b * n + row) * c4 + c) * 4;
             atomicAdd(df + 0, g_fd.x * d + g_f.x); atomicAdd(df + 1, g_fd.y * d + g_f.y);
@@ -185,8 +191,8 @@ static bool ragged_c_ok(int c) { return c == 16 || c == 32 || c == 64 || c == 12
 
 }  // namespace pda
 
-PDA_API int pda_ragged_plan(const int32_t* idx, int32_t* cnt, int32_t* off, int32_t* rowmap, int64_t groups, int nsample,
-                            pda_stream_t stream) {
+PDA_API int pda_ragged_plan(const int32_t* idx, int32_t* cnt, int32_t* off, int32_t* rowmap, float* row_weight, int64_t groups,
+                            int nsample, pda_stream_t stream) {
     PDA_REQUIRE(groups >= 0 && groups <= (1 << 24) && nsample >= 1 && nsample <= 255 && groups * nsample < INT32_MAX,
                 "pda_ragged_plan: groups=%lld nsample=%d", (long long)groups, nsample);
     PDA_REQUIRE(off != nullptr, "pda_ragged_plan: null pointer");
@@ -195,14 +201,14 @@ PDA_API int pda_ragged_plan(const int32_t* idx, int32_t* cnt, int32_t* off, int3
     if (groups > 0) {
         const int64_t total = groups * nsample;
         hipLaunchKernelGGL(pda::ragged_rowmap_kernel, dim3((unsigned)pda::divup64(total, 256)), dim3(256), 0, (hipStream_t)stream, cnt,
-                           off, rowmap, total, nsample);
+                           off, rowmap, row_weight, total, nsample);
     }
     return pda::check_launch("pda_ragged_plan");
 }
 
 PDA_API int pda_assemble_tokens_ragged(const float* rppe, const float* dscale, const float* feats, const int32_t* idx,
                                        const float* glob, const int32_t* rowmap, const int32_t* off, float* out, int64_t max_tokens,
-                                       int b, int n, int m, int nsample, int c, pda_stream_t stream) {
+                                       int b, int n, int m, int nsample, int c, int rppe_compact, pda_stream_t stream) {
     PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && max_tokens >= 0 && pda::ragged_c_ok(c),
                 "pda_assemble_tokens_ragged: b=%d n=%d m=%d nsample=%d C=%d", b, n, m, nsample, c);
     const int64_t total = max_tokens * (c / 4);
@@ -210,14 +216,14 @@ PDA_API int pda_assemble_tokens_ragged(const float* rppe, const float* dscale, c
     PDA_REQUIRE(rppe && dscale && feats && idx && glob && rowmap && off && out, "pda_assemble_tokens_ragged: null pointer");
     PDA_REQUIRE((((uintptr_t)rppe | (uintptr_t)feats | (uintptr_t)glob | (uintptr_t)out) & 15) == 0, "pda_assemble_tokens_ragged: alignment");
     hipLaunchKernelGGL(pda::assemble_ragged_fwd_kernel, dim3((unsigned)pda::divup64(total, 256)), dim3(256), 0, (hipStream_t)stream, rppe,
-                       dscale, feats, idx, glob, rowmap, off, out, n, m, nsample, c / 4, b * m);
+                       dscale, feats, idx, glob, rowmap, off, out, n, m, nsample, c / 4, b * m, rppe_compact);
     return pda::check_launch("pda_assemble_tokens_ragged");
 }
 
 PDA_API int pda_assemble_tokens_ragged_grad(const float* grad_out, const float* dscale, const float* feats, const int32_t* idx,
                                             const int32_t* cnt, const int32_t* off, float* grad_rppe, float* grad_dscale,
                                             float* grad_feats, float* grad_glob, int b, int n, int m, int nsample, int c,
-                                            pda_stream_t stream) {
+                                            int rppe_compact, pda_stream_t stream) {
     PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && pda::ragged_c_ok(c),
                 "pda_assemble_tokens_ragged_grad: b=%d n=%d m=%d nsample=%d C=%d", b, n, m, nsample, c);
     const int64_t centre_cols = (int64_t)b * m * (c / 4);
@@ -229,7 +235,7 @@ PDA_API int pda_assemble_tokens_ragged_grad(const float* grad_out, const float* 
     const dim3 grid((unsigned)pda::divup64(centre_cols, 256)), block(256);
 #define PDA_ASM_BWD(C4)                                                                                                          \
     case C4: hipLaunchKernelGGL(pda::assemble_ragged_bwd_kernel<C4>, grid, block, 0, (hipStream_t)stream, grad_out, dscale, feats, idx, \
-                                cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, n, m, nsample, centre_cols); break
+                                cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, n, m, nsample, centre_cols, rppe_compact); break
     switch (c / 4) { PDA_ASM_BWD(4); PDA_ASM_BWD(8); PDA_ASM_BWD(16); PDA_ASM_BWD(32); PDA_ASM_BWD(64); }
 #undef PDA_ASM_BWD
     return pda::check_launch("pda_assemble_tokens_ragged_grad");

@@ -473,32 +473,57 @@ def assemble_tokens_grad(grad_out, dscale, feats, idx, grad_rppe, grad_dscale, g
 
 
 # ---- unique-token ("ragged") execution of a PDA scale (include/pda_train.h, csrc/ragged.hip) --------------------
-def ragged_plan(idx, cnt, off, rowmap, groups, nsample):
-    """idx (groups, nsample) -> cnt (groups), off (groups + 1), rowmap (groups * nsample capacity).  No synchronisation."""
+def ragged_plan(idx, cnt, off, rowmap, groups, nsample, roww=None):
+    """idx (groups, nsample) -> cnt (groups), off (groups + 1), rowmap and (optional) roww, the multiplicity of each compact
+    token (groups * nsample capacity).  No synchronisation."""
     _numel_ok(idx, groups * nsample, "idx"); _numel_ok(cnt, groups, "cnt"); _numel_ok(off, groups + 1, "off")
     _numel_ok(rowmap, groups * nsample, "rowmap")
+    if roww is not None:
+        _numel_ok(roww, groups * nsample, "roww")
     _call("pda_ragged_plan", idx, _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(rowmap, "rowmap", I32),
-          groups, nsample)
+          None if roww is None else _chk(roww, "roww", F32), groups, nsample)
     return 1
 
 
-def assemble_tokens_ragged(rppe, dscale, feats, idx, glob, rowmap, off, out, tokens, b, n, m, nsample, c):
+def bn_relu_fwd_weighted(x, gamma, beta, running_mean, running_var, y, mean_invstd, scratch, rows, c, eps, momentum, roww, count):
+    """MI355X extension: bn_relu_fwd on rows that stand for roww[r] identical rows of a dense tensor of `count` rows."""
+    _numel_ok(x, rows * c, "x"); _numel_ok(y, rows * c, "y"); _numel_ok(mean_invstd, 2 * c, "mean_invstd"); _numel_ok(roww, rows, "roww")
+    rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
+    rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _buffers_written(rm)
+    _call("pda_bn_relu_fwd_weighted", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32), rm, rv, _chk(y, "y", F32),
+          _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8), rows, c, float(eps), float(momentum),
+          _chk(roww, "roww", F32), int(count))
+    return 1
+
+
+def bn_relu_bwd_weighted(x, grad_y, gamma, beta, mean_invstd, grad_x, grad_gamma, grad_beta, scratch, rows, c, roww, count):
+    _numel_ok(x, rows * c, "x"); _numel_ok(grad_y, rows * c, "grad_y"); _numel_ok(grad_x, rows * c, "grad_x"); _numel_ok(roww, rows, "roww")
+    _call("pda_bn_relu_bwd_weighted", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32),
+          _chk(mean_invstd, "mean_invstd", F32), _chk(grad_x, "grad_x", F32), _chk(grad_gamma, "grad_gamma", F32),
+          _chk(grad_beta, "grad_beta", F32), _chk(scratch, "scratch", torch.uint8), rows, c, _chk(roww, "roww", F32), int(count))
+    return 1
+
+
+def assemble_tokens_ragged(rppe, dscale, feats, idx, glob, rowmap, off, out, tokens, b, n, m, nsample, c, rppe_compact=False):
     t = b * m * nsample
-    _numel_ok(rppe, t * c, "rppe"); _numel_ok(dscale, t, "dscale"); _numel_ok(feats, b * n * c, "feats"); _numel_ok(idx, t, "idx")
+    _numel_ok(rppe, (tokens if rppe_compact else t) * c, "rppe"); _numel_ok(dscale, t, "dscale"); _numel_ok(feats, b * n * c, "feats"); _numel_ok(idx, t, "idx")
     _numel_ok(glob, b * m * c, "glob"); _numel_ok(out, tokens * 4 * c, "out"); _numel_ok(rowmap, tokens, "rowmap"); _numel_ok(off, b * m + 1, "off")
     _call("pda_assemble_tokens_ragged", rppe, _chk(rppe, "rppe", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
           _chk(idx, "idx", I32), _chk(glob, "glob", F32), _chk(rowmap, "rowmap", I32), _chk(off, "off", I32), _chk(out, "out", F32),
-          tokens, b, n, m, nsample, c)
+          tokens, b, n, m, nsample, c, 1 if rppe_compact else 0)
     return 1
 
 
-def assemble_tokens_ragged_grad(grad_out, dscale, feats, idx, cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, tokens, b, n, m, nsample, c):
+def assemble_tokens_ragged_grad(grad_out, dscale, feats, idx, cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, tokens, b, n, m, nsample, c,
+                                rppe_compact=False):
     t = b * m * nsample
-    _numel_ok(grad_out, tokens * 4 * c, "grad_out"); _numel_ok(grad_rppe, t * c, "grad_rppe"); _numel_ok(grad_dscale, t, "grad_dscale")
+    _numel_ok(grad_out, tokens * 4 * c, "grad_out"); _numel_ok(grad_rppe, (tokens if rppe_compact else t) * c, "grad_rppe"); _numel_ok(grad_dscale, t, "grad_dscale")
     _numel_ok(grad_feats, b * n * c, "grad_feats"); _numel_ok(grad_glob, b * m * c, "grad_glob"); _numel_ok(cnt, b * m, "cnt"); _numel_ok(off, b * m + 1, "off")
     _call("pda_assemble_tokens_ragged_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
           _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_rppe, "grad_rppe", F32),
-          _chk(grad_dscale, "grad_dscale", F32), _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c)
+          _chk(grad_dscale, "grad_dscale", F32), _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c,
+          1 if rppe_compact else 0)
     return 1
 
 

@@ -691,8 +691,16 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                         dscale = _linear_relu(dscale, *_folded_conv_bn(conv, bn))
                     else:
                         dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
-            rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
+            if (plans[i] is not None and feats_pm.shape[-1] in (16, 32, 64, 128, 256) and FUSED_BN_RELU
+                    and pointnet2_utils.FUSED_ASSEMBLE and pointnet2_utils.position_mlp_ragged_supported(self.position_mlp[i], rppe)):
+                # position MLP, token assembly and encoder all on the distinct tokens
+                rppe_c = pointnet2_utils.position_mlp_ragged(self.position_mlp[i], rppe, plans[i])        # (U, C)
+                x = pointnet2_utils.AssembleTokensRagged.apply(rppe_c, dscale, feats_pm, idxs[i], glob, plans[i])
+                x = pointnet2_utils.ragged_transformer_block(self.Local_pointformer[i], x, plans[i]).view(B, npoint, -1)
+                outs.append(_mlp_lastdim(self.fin_conv[i], x))
+                continue
+            rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             if plans[i] is not None and pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
                 # the encoder on the distinct tokens only (csrc/ragged.hip): x (U, 4C) -> (B, M, 4C)
                 x = pointnet2_utils.AssembleTokensRagged.apply(rppe, dscale, feats_pm, idxs[i], glob, plans[i])

@@ -903,10 +903,11 @@ RAGGED_MAX_FRACTION = 0.85
 
 class RaggedPlan:
     """cnt (G) / off (G+1) / rowmap (U) of one scale (device tensors) and U, the number of distinct tokens (host int)."""
-    __slots__ = ("cnt", "off", "rowmap", "tokens", "groups", "nsample")
+    __slots__ = ("cnt", "off", "rowmap", "roww", "tokens", "groups", "nsample")
 
-    def __init__(self, cnt, off, rowmap, tokens, groups, nsample):
-        self.cnt, self.off, self.rowmap, self.tokens, self.groups, self.nsample = cnt, off, rowmap, tokens, groups, nsample
+    def __init__(self, cnt, off, rowmap, roww, tokens, groups, nsample):
+        self.cnt, self.off, self.rowmap, self.roww = cnt, off, rowmap, roww      # roww: multiplicity of each compact token
+        self.tokens, self.groups, self.nsample = tokens, groups, nsample
 
     @property
     def fraction(self):
@@ -922,13 +923,14 @@ def ragged_plan_parts(idxs):
         cnt = torch.empty((G,), dtype=torch.int32, device=idx.device)
         off = torch.empty((G + 1,), dtype=torch.int32, device=idx.device)
         rowmap = torch.empty((G * ns,), dtype=torch.int32, device=idx.device)
-        pointnet2.ragged_plan(idx, cnt, off, rowmap, G, ns)
-        parts.append((cnt, off, rowmap, G, ns))
+        roww = torch.empty((G * ns,), dtype=torch.float32, device=idx.device)
+        pointnet2.ragged_plan(idx, cnt, off, rowmap, G, ns, roww)
+        parts.append((cnt, off, rowmap, roww, G, ns))
     return parts, torch.stack([p[1][-1] for p in parts])
 
 
 def ragged_plans_from(parts, totals):
-    return [RaggedPlan(c, o, r[:u], int(u), G, ns) for (c, o, r, G, ns), u in zip(parts, totals)]
+    return [RaggedPlan(c, o, r[:u], w[:u], int(u), G, ns) for (c, o, r, w, G, ns), u in zip(parts, totals)]
 
 
 def ragged_plans(idxs):
@@ -941,32 +943,94 @@ def ragged_plans(idxs):
 
 
 class AssembleTokensRagged(Function):
-    """AssembleTokens writing only the distinct tokens: x (U, 4C).  The gradients of rppe / dscale come back dense
-    (B,M,ns,.) with zeros at the repeat slots -- the position MLP and DensityNet in front of this still run dense."""
+    """AssembleTokens writing only the distinct tokens: x (U, 4C).  rppe is either dense (B,M,ns,C) -- its gradient then
+    comes back dense with zeros at the repeat slots -- or compact (U, C) when the position MLP ran on the distinct tokens
+    (RAGGED_POSITION_MLP); dscale is dense (B,M,ns,1) either way (DensityNet runs on all slots)."""
 
     @staticmethod
     def forward(ctx, rppe, dscale, feats_pm, idx, glob, plan):
-        B, M, ns, C = rppe.shape
-        N = feats_pm.shape[1]
+        B, M, ns = idx.shape
+        C, N = feats_pm.shape[-1], feats_pm.shape[1]
+        compact = rppe.dim() == 2
         rppe, dscale, feats_pm, glob = rppe.contiguous(), dscale.contiguous(), feats_pm.contiguous(), glob.contiguous()
         out = torch.empty((plan.tokens, 4 * C), dtype=torch.float32, device=rppe.device)
-        pointnet2.assemble_tokens_ragged(rppe, dscale, feats_pm, idx, glob, plan.rowmap, plan.off, out, plan.tokens, B, N, M, ns, C)
+        pointnet2.assemble_tokens_ragged(rppe, dscale, feats_pm, idx, glob, plan.rowmap, plan.off, out, plan.tokens, B, N, M, ns, C,
+                                         rppe_compact=compact)
         ctx.save_for_backward(dscale, feats_pm, idx, plan.cnt, plan.off)
-        ctx.dims = (B, N, M, ns, C, plan.tokens)
+        ctx.dims = (B, N, M, ns, C, plan.tokens, compact)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
         dscale, feats_pm, idx, cnt, off = ctx.saved_tensors
-        B, N, M, ns, C, U = ctx.dims
+        B, N, M, ns, C, U, compact = ctx.dims
         dev = grad_out.device
-        g_rppe = torch.empty((B, M, ns, C), dtype=torch.float32, device=dev)
+        g_rppe = torch.empty((U, C) if compact else (B, M, ns, C), dtype=torch.float32, device=dev)
         g_ds = torch.empty_like(dscale)
         g_feats = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
         g_glob = torch.empty((B, M, C), dtype=torch.float32, device=dev)
         pointnet2.assemble_tokens_ragged_grad(grad_out.contiguous(), dscale, feats_pm, idx, cnt, off, g_rppe, g_ds, g_feats, g_glob,
-                                              U, B, N, M, ns, C)
+                                              U, B, N, M, ns, C, rppe_compact=compact)
         return g_rppe, g_ds, g_feats, None, g_glob, None
+
+
+# The position MLP of a PDA scale (pointnet2_modules.py:907-915: Conv 12 -> C/2 -> C with BatchNorm + ReLU) on the distinct
+# tokens: the rows are gathered, the convolutions run on (U, .) and the BatchNorms use multiplicity-weighted statistics, i.e.
+# exactly the statistics of the dense (B, M, ns, .) tensor (csrc/bn_relu.hip, pda_bn_relu_{fwd,bwd}_weighted).
+RAGGED_POSITION_MLP = True
+
+
+class BatchNormReLUWeighted(Function):
+    """relu(batch_norm(x)) in training mode on rows that stand for roww[r] copies each (dense row count = `count`)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, running_mean, running_var, eps, momentum, roww, count):
+        x = x.contiguous()
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        stats = torch.empty((2 * c,), dtype=torch.float32, device=x.device)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_fwd_weighted(x, weight, bias, running_mean, running_var, y, stats, scratch, rows, c, eps, momentum, roww, count)
+        ctx.save_for_backward(x, weight, bias, stats, roww)
+        ctx.count = count
+        return y
+
+    @staticmethod
+    def backward(ctx, grad_y):
+        x, weight, bias, stats, roww = ctx.saved_tensors
+        rows, c = x.shape
+        gx = torch.empty_like(x)
+        gw, gb = torch.empty_like(weight), torch.empty_like(bias)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c),), dtype=torch.uint8, device=x.device)
+        pointnet2.bn_relu_bwd_weighted(x, grad_y.contiguous(), weight, bias, stats, gx, gw, gb, scratch, rows, c, roww, ctx.count)
+        return gx, gw, gb, None, None, None, None, None, None
+
+
+def position_mlp_ragged_supported(layers, rppe):
+    layers = list(layers)
+    ok = (RAGGED_POSITION_MLP and rppe.is_cuda and rppe.dtype == torch.float32 and len(layers) == 6 and torch.is_grad_enabled()
+          and not DENSE_BF16 and not torch.is_autocast_enabled())
+    if not ok:
+        return False
+    for conv, bn in ((layers[0], layers[1]), (layers[3], layers[4])):
+        c = conv.weight.shape[0]
+        if (conv.bias is not None or not bn.training or not bn.affine or bn.momentum is None or c < 4 or c > 1024
+                or (c & (c - 1)) != 0):
+            return False
+    return True
+
+
+def position_mlp_ragged(layers, rppe, plan):
+    """[Conv -> BN -> ReLU] x 2 of `layers` on the distinct tokens: rppe (B,M,ns,12) dense in, (U, C) compact out."""
+    layers = list(layers)
+    x = rppe.reshape(-1, rppe.shape[-1]).index_select(0, plan.rowmap)        # (U, 12)
+    count = plan.groups * plan.nsample
+    for conv, bn in ((layers[0], layers[1]), (layers[3], layers[4])):
+        x = torch.nn.functional.linear(x, conv.weight.flatten(1))
+        rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
+        bump_bn_counter(bn)
+        x = BatchNormReLUWeighted.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, plan.roww, count)
+    return x
 
 
 def _wgrad_ragged(x2d, g2d, weight, want_bias):

@@ -159,7 +159,7 @@ def test_fused_and_unfused_training_steps_agree():
     from pdanet_amd import synth, pointnet2_modules as pm, pointnet2_utils as pu
     from pdanet_amd.backbone import build_backbone
     flags = [(pm, "GROUP_ATTENTION_KERNEL"), (pm, "FUSED_BN_RELU"), (pm, "FUSED_LAYER_NORM"), (pm, "FUSED_TRANSFORMER_BLOCK"),
-             (pm, "FUSED_GEOMETRY"), (pm, "FUSED_BN_RELU_MAX_POOL"), (pu, "LINEAR_WGRAD_KERNEL"), (pu, "FUSED_DENSITYNET"), (pu, "FUSED_ASSEMBLE"), (pu, "RAGGED_TOKENS")]
+             (pm, "FUSED_GEOMETRY"), (pm, "FUSED_BN_RELU_MAX_POOL"), (pu, "LINEAR_WGRAD_KERNEL"), (pu, "FUSED_DENSITYNET"), (pu, "FUSED_ASSEMBLE"), (pu, "RAGGED_TOKENS"), (pu, "RAGGED_POSITION_MLP"), (pu, "SA_MFMA_TRAIN")]
     B, N = 2, 4096
     pts = torch.from_numpy(synth.batch_points(B, N, config_id=2, dist="L")).cuda()
     results = []

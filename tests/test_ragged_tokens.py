@@ -136,3 +136,38 @@ def test_dense_scale_is_left_alone_above_the_fraction_threshold():
     idx, _ = padded_idx(64, 16, 2000, rng, p_single=0.0, p_full=1.0, empty_rows=0)
     (plan,) = pu.ragged_plans([torch.from_numpy(idx).cuda().view(1, 64, 16)])
     assert plan.tokens == 64 * 16 and plan.fraction == 1.0 > pu.RAGGED_MAX_FRACTION
+
+
+@pytest.mark.parametrize("G,S,C", [(300, 16, 32), (1000, 32, 64), (77, 8, 128)])
+def test_weighted_batch_norm_equals_dense_batch_norm_on_expanded_rows(G, S, C):
+    """pda_bn_relu_{fwd,bwd}_weighted on the compact rows == the plain kernels on the dense (G*S, C) tensor in which token 0
+    of every group is repeated: same y, same running statistics, and the compact gradient is the sum over the copies."""
+    from pdanet_amd import pointnet2_utils as pu
+    rng = np.random.default_rng(G + C)
+    idx, cnt = padded_idx(G, S, 4000, rng)
+    (plan,) = pu.ragged_plans([torch.from_numpy(idx).cuda().view(1, G, S)])
+    U = plan.tokens
+    assert float(plan.roww.sum()) == G * S
+    g = torch.Generator("cuda").manual_seed(C)
+    xc = torch.randn(U, C, device="cuda", generator=g).requires_grad_(True)
+    slot = torch.arange(S, device="cuda").view(1, S)
+    src = plan.off.long()[:-1].view(G, 1) + torch.where(slot < plan.cnt.long().view(G, 1), slot, torch.zeros_like(slot))
+    xd = xc.detach()[src].reshape(G * S, C).requires_grad_(True)
+    bn_c, bn_d = torch.nn.BatchNorm1d(C).cuda().train(), torch.nn.BatchNorm1d(C).cuda().train()
+    with torch.no_grad():
+        for b in (bn_c, bn_d):
+            b.weight.copy_(torch.linspace(0.5, 1.5, C)); b.bias.copy_(torch.linspace(-0.3, 0.3, C))
+    yc = pu.BatchNormReLUWeighted.apply(xc, bn_c.weight, bn_c.bias, bn_c.running_mean, bn_c.running_var, bn_c.eps, bn_c.momentum,
+                                        plan.roww, G * S)
+    yd = pu.batch_norm_relu(bn_d, xd)
+    assert (yd.view(G, S, C) - yc[src]).abs().max().item() < 2e-5
+    assert torch.allclose(bn_c.running_mean, bn_d.running_mean, atol=1e-6) and torch.allclose(bn_c.running_var, bn_d.running_var, rtol=1e-5)
+    go_c = torch.randn(U, C, device="cuda", generator=g)
+    valid = slot < plan.cnt.long().view(G, 1)
+    go_d = torch.where(valid.unsqueeze(-1), go_c[src], torch.zeros((), device="cuda")).reshape(G * S, C)    # total on one copy
+    gc = torch.autograd.grad(yc, (xc, bn_c.weight, bn_c.bias), go_c)
+    gd = torch.autograd.grad(yd, (xd, bn_d.weight, bn_d.bias), go_d)
+    ref = torch.zeros_like(gc[0]).index_add_(0, src.reshape(-1), gd[0])
+    assert (ref - gc[0]).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
+    for a, b in zip(gc[1:], gd[1:]):
+        assert (a - b).abs().max().item() < 1e-4 * max(1.0, b.abs().max().item())
