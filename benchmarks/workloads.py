@@ -522,6 +522,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         # head + losses replayed as hipGraphs (detector.IASSD.graph_head); DDP runs keep the eager head (a two-rank
         # rehearsal with the graphed head under DDP crashed in capture: not pursued without multi-GPU hardware)
         self.model.graph_head = world == 1 and os.environ.get("PDA_GRAPH_HEAD", "1") != "0"
+        self.model.graph_tail = world == 1 and os.environ.get("PDA_GRAPH_TAIL", "0") != "0"
         self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
         self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None

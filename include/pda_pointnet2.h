@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 14
+#define PDA_POINTNET2_ABI_VERSION 15
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);
@@ -220,6 +220,16 @@ int pda_linear_cols(const float *x, const float *wf, float *y, int64_t tokens, i
 int pda_sa_gather_linear(const float *xyz, const float *new_xyz, const float *feats_pm, const int32_t *idx,
                          const float *wf, float *y, int b, int n, int m, int c, int nsample, int n_out,
                          pda_stream_t stream);
+/* The same contraction on the bf16 matrix cores with f32 operands split into three bf16 terms each (csrc/gemm_split.hip:
+ * x = h + m + l exactly; six of the nine cross products are kept, the dropped ones are below 2^-24 of the product; f32
+ * accumulate): f32-grade results at 2.67x the f32 MFMA rate.  Replaces the same cuDNN/cuBLAS f32 calls as pda_linear_cols.
+ *   pda_linear_split:  y (tokens, n_out) = x (tokens, k) W^T [+ bias] [relu];  k a multiple of 32 <= 512, n_out a multiple
+ *                      of 128;  wf = pda_linear_split_pack(W (n_out, k)); transposed_source = 1: w holds W^T (k, n_out).
+ * PDA_ERR_UNSUPPORTED for other shapes. */
+int64_t pda_linear_split_packed_bytes(int n_out, int k);
+int pda_linear_split_pack(const float *w, void *wf, int n_out, int k, int transposed_source, pda_stream_t stream);
+int pda_linear_split(const float *x, const void *wf, const float *bias, float *y, int64_t tokens, int k, int n_out,
+                     int relu, pda_stream_t stream);
 /* Number of floats pda_sa_mlp_pack_weights writes for a (rows x cols) layer. */
 int pda_sa_mlp_packed_size(int rows, int cols, int first_layer);
 /* Re-orders a row-major (rows x cols) fp32 weight matrix into MFMA A-fragment order. */

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -53,6 +53,9 @@ SIGNATURES = {
     "pda_linear_cols_pack": [_vp, _vp, _i, _i, _i, _i, _vp],
     "pda_linear_cols": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_sa_gather_linear": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "pda_linear_split_packed_bytes": [_i, _i],
+    "pda_linear_split_pack": [_vp, _vp, _i, _i, _i, _vp],
+    "pda_linear_split": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],
     "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
     # include/pda_train.h
@@ -140,6 +143,7 @@ def load():
     lib.pda_bn_relu_scratch_bytes.restype = ctypes.c_int64
     lib.pda_layer_norm_scratch_bytes.restype = ctypes.c_int64
     lib.pda_linear_wgrad_scratch_bytes.restype = ctypes.c_int64
+    lib.pda_linear_split_packed_bytes.restype = ctypes.c_int64
     lib.pda_colsum_scratch_bytes.restype = ctypes.c_int64
     lib.pda_densitynet_scratch_bytes.restype = ctypes.c_int64
     lib.pda_abi_version.restype = _i

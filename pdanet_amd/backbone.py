@@ -11,6 +11,8 @@ Differences (results unchanged): the per-scene point count is taken from the ten
 per forward, :131-137), and the D-FPS of layer k+1 can be launched on a side stream when it
 depends only on coordinates (see `prefetch_fps`).
 """
+import contextlib
+
 import torch
 import torch.nn as nn
 
@@ -156,17 +158,31 @@ class IASSD_Backbone(nn.Module):
     def forward(self, batch_dict):
         """batch_dict: batch_size, points (B*N, 1 + 3 + C) [bs_idx, x, y, z, ...] with the same N
         for every scene (IASSD_backbone.py:137).  Adds the reference's output keys (:188-203)."""
-        if not self.training:
+        with self.bn_counters():
             return self._forward(batch_dict)
+
+    @contextlib.contextmanager
+    def bn_counters(self):
+        """Training: the num_batches_tracked bumps of every BatchNorm touched inside are applied as ONE _foreach_add_."""
+        if not self.training or pointnet2_utils.BN_COUNTERS_PENDING is not None:
+            yield
+            return
         pointnet2_utils.BN_COUNTERS_PENDING = pending = []   # see pointnet2_utils.bump_bn_counter
         try:
-            return self._forward(batch_dict)
+            yield
         finally:
             pointnet2_utils.BN_COUNTERS_PENDING = None
             if pending:
                 torch._foreach_add_(pending, 1)
 
     def _forward(self, batch_dict):
+        st = self._begin(batch_dict)
+        for i in range(len(self.SA_modules)):
+            self._run_layer(i, st)
+        return self._finish(batch_dict, st)
+
+    # ---- the forward pass as explicit steps over a state dict (detector.IASSD replays a static tail as hipGraphs) ------
+    def _begin(self, batch_dict):
         batch_size = batch_dict['batch_size']
         points = batch_dict['points']
         batch_idx, xyz, features = self.break_up_pc(points)
@@ -174,67 +190,76 @@ class IASSD_Backbone(nn.Module):
         xyz = xyz.view(batch_size, -1, 3)
         features = features.view(batch_size, -1, features.shape[-1]).permute(0, 2, 1).contiguous() \
             if features is not None else None
-
-        encoder_xyz, encoder_features, sa_ins_preds = [xyz], [features], []
-        encoder_sample_list_id = []
-        encoder_coords = [torch.cat([batch_idx.view(batch_size, -1, 1), xyz], dim=-1)]
-        bidx = batch_idx.view(batch_size, -1)
-
-        li_cls_pred = None
-        sample_list_id = []
+        st = dict(batch_size=batch_size, encoder_xyz=[xyz], encoder_features=[features], sa_ins_preds=[], sample_ids=[],
+                  encoder_coords=[torch.cat([batch_idx.view(batch_size, -1, 1), xyz], dim=-1)],
+                  bidx=batch_idx.view(batch_size, -1), li_cls_pred=None, presampled={})
         resident = bool(batch_dict.get('inputs_resident', False))
-        presampled = {}
         if self.prefetch_sampling:
             stash, self._prefetched = self._prefetched, None
             if stash is not None and stash[0] == (points.data_ptr(), tuple(points.shape), points._version, batch_size):
-                presampled = stash[1]                       # started by prefetch() during the previous iteration
+                st['presampled'] = stash[1]                 # started by prefetch() during the previous iteration
             else:
-                presampled = self._presample(xyz, points if resident else None, batch_size)
-        for i in range(len(self.SA_modules)):
-            xyz_input = encoder_xyz[self.layer_inputs[i]]
-            feature_input = encoder_features[self.layer_inputs[i]]
-            if self.layer_types[i] == 'SA_Layer':
-                ctr_xyz = encoder_xyz[self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
-                pre = None
-                if i in presampled:
-                    ev, pidx, pxyz, pq = presampled[i]
-                    torch.cuda.current_stream(xyz.device).wait_event(ev)
-                    if pq is not None and pq['totals'] is not None:
-                        ev.synchronize()                     # the token counts in pinned memory (side stream only: no drain)
-                    pre = (pidx, pxyz, pq)
-                li_xyz, li_features, li_cls_pred, sample_list_id = self.SA_modules[i](
-                    xyz_input, feature_input, li_cls_pred, ctr_xyz=ctr_xyz, presampled=pre)
-            elif self.layer_types[i] == 'Vote_Layer':
-                li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input)
-                centers = li_xyz
-                centers_origin = xyz_select
-                center_origin_batch_idx = bidx[:, :centers_origin.shape[1]]
-                encoder_coords.append(torch.cat([center_origin_batch_idx[..., None].float(),
-                                                 centers_origin.view(batch_size, -1, 3)], dim=-1))
-            encoder_xyz.append(li_xyz)
-            li_batch_idx = bidx[:, :li_xyz.shape[1]]
-            encoder_coords.append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
-            encoder_features.append(li_features)
-            encoder_sample_list_id.append(sample_list_id)
-            if li_cls_pred is not None:
-                li_cls_batch_idx = bidx[:, :li_cls_pred.shape[1]]
-                sa_ins_preds.append(torch.cat([li_cls_batch_idx[..., None].float(),
-                                               li_cls_pred.view(batch_size, -1, li_cls_pred.shape[-1])], dim=-1))
-            else:
-                sa_ins_preds.append([])
+                st['presampled'] = self._presample(xyz, points if resident else None, batch_size)
+        return st
 
-        ctr_batch_idx = bidx[:, :li_xyz.shape[1]].contiguous().view(-1)
-        batch_dict['ctr_offsets'] = torch.cat((ctr_batch_idx[:, None].float(), ctr_offsets.contiguous().view(-1, 3)), dim=1)
-        batch_dict['centers'] = torch.cat((ctr_batch_idx[:, None].float(), centers.contiguous().view(-1, 3)), dim=1)
-        batch_dict['centers_origin'] = torch.cat((ctr_batch_idx[:, None].float(), centers_origin.contiguous().view(-1, 3)), dim=1)
-        center_features = encoder_features[-1].permute(0, 2, 1).contiguous().view(-1, encoder_features[-1].shape[1])
-        batch_dict['centers_features'] = center_features
+    def first_static_tail_layer(self):
+        """Index of the first layer after which nothing reads a token count on the host (the layers behind the last PDA
+        layer with groupers): from there to the losses every shape is static."""
+        last = -1
+        for i, m in enumerate(self.SA_modules):
+            if isinstance(m, pointnet2_modules.PointnetSAModuleMSG_WithSampling_Ellipsoid) and len(m.groupers) > 0:
+                last = i
+        return last + 1
+
+    def _run_layer(self, i, st):
+        batch_size, bidx = st['batch_size'], st['bidx']
+        xyz_input = st['encoder_xyz'][self.layer_inputs[i]]
+        feature_input = st['encoder_features'][self.layer_inputs[i]]
+        sample_list_id = []
+        if self.layer_types[i] == 'SA_Layer':
+            ctr_xyz = st['encoder_xyz'][self.ctr_idx_list[i]] if self.ctr_idx_list[i] != -1 else None
+            pre = None
+            if i in st['presampled']:
+                ev, pidx, pxyz, pq = st['presampled'][i]
+                torch.cuda.current_stream(xyz_input.device).wait_event(ev)
+                if pq is not None and pq['totals'] is not None:
+                    ev.synchronize()                     # the token counts in pinned memory (side stream only: no drain)
+                pre = (pidx, pxyz, pq)
+            li_xyz, li_features, st['li_cls_pred'], sample_list_id = self.SA_modules[i](
+                xyz_input, feature_input, st['li_cls_pred'], ctr_xyz=ctr_xyz, presampled=pre)
+        elif self.layer_types[i] == 'Vote_Layer':
+            li_xyz, li_features, xyz_select, ctr_offsets = self.SA_modules[i](xyz_input, feature_input)
+            st['centers'], st['centers_origin'], st['ctr_offsets'] = li_xyz, xyz_select, ctr_offsets
+            center_origin_batch_idx = bidx[:, :xyz_select.shape[1]]
+            st['encoder_coords'].append(torch.cat([center_origin_batch_idx[..., None].float(),
+                                                   xyz_select.view(batch_size, -1, 3)], dim=-1))
+        st['encoder_xyz'].append(li_xyz)
+        li_batch_idx = bidx[:, :li_xyz.shape[1]]
+        st['encoder_coords'].append(torch.cat([li_batch_idx[..., None].float(), li_xyz.view(batch_size, -1, 3)], dim=-1))
+        st['encoder_features'].append(li_features)
+        st['sample_ids'].append(sample_list_id)
+        li_cls_pred = st['li_cls_pred']
+        if li_cls_pred is not None:
+            li_cls_batch_idx = bidx[:, :li_cls_pred.shape[1]]
+            st['sa_ins_preds'].append(torch.cat([li_cls_batch_idx[..., None].float(),
+                                                 li_cls_pred.view(batch_size, -1, li_cls_pred.shape[-1])], dim=-1))
+        else:
+            st['sa_ins_preds'].append([])
+
+    def _finish(self, batch_dict, st):
+        li_xyz = st['encoder_xyz'][-1]
+        ctr_batch_idx = st['bidx'][:, :li_xyz.shape[1]].contiguous().view(-1)
+        batch_dict['ctr_offsets'] = torch.cat((ctr_batch_idx[:, None].float(), st['ctr_offsets'].contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers'] = torch.cat((ctr_batch_idx[:, None].float(), st['centers'].contiguous().view(-1, 3)), dim=1)
+        batch_dict['centers_origin'] = torch.cat((ctr_batch_idx[:, None].float(), st['centers_origin'].contiguous().view(-1, 3)), dim=1)
+        feats = st['encoder_features'][-1]
+        batch_dict['centers_features'] = feats.permute(0, 2, 1).contiguous().view(-1, feats.shape[1])
         batch_dict['ctr_batch_idx'] = ctr_batch_idx
-        batch_dict['encoder_xyz'] = encoder_xyz
-        batch_dict['encoder_coords'] = encoder_coords
-        batch_dict['sa_ins_preds'] = sa_ins_preds
-        batch_dict['encoder_features'] = encoder_features
-        batch_dict['sample_list_id'] = encoder_sample_list_id
+        batch_dict['encoder_xyz'] = st['encoder_xyz']
+        batch_dict['encoder_coords'] = st['encoder_coords']
+        batch_dict['sa_ins_preds'] = st['sa_ins_preds']
+        batch_dict['encoder_features'] = st['encoder_features']
+        batch_dict['sample_list_id'] = st['sample_ids']
         return batch_dict
 
 

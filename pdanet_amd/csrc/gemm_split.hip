@@ -1,0 +1,271 @@
+// gemm_split.hip -- f32 GEMMs of the training step on the bf16 matrix cores, operands split into three bf16 terms.
+//
+// MI355X has no xf32/TF32 form and its f32-input MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 rate
+// (157 TFLOP/s against ~2.5 PFLOP/s, MI355X_MICROARCH.md "Matrix cores").  An f32 value x is EXACTLY the sum of
+// three bf16 values (8 + 8 + 8 significant bits, same exponent range):
+//     h = bf16(x),  m = bf16(x - h),  l = bf16(x - h - m),      x = h + m + l,
+// so a product a*b = sum of nine bf16*bf16 products, each exact in f32.  This file keeps the six largest,
+//     ah*bh + ah*bm + am*bh + am*bm + ah*bl + al*bh,
+// and drops am*bl, al*bm, al*bl (relative size <= 2^-24 each: below the rounding of an f32 multiply).  The sums
+// accumulate in the MFMA's f32 accumulator like the f32-input form's do.  Six v_mfma_f32_32x32x16_bf16 (6 x 32
+// cycles) replace eight v_mfma_f32_32x32x2_f32 (8 x 64 cycles): 2.67x the f32 matrix rate at f32 accuracy
+// (tests/test_gemm_split.py measures both against an f64 product).
+//
+// Replaces the reference's cuDNN/cuBLAS f32 1x1 convolutions and nn.Linear calls of the group MLPs
+// (/root/reference/pcdet/ops/pointnet2/pointnet2_batch/pointnet2_modules.py:1657-1662) in training.
+//
+//   lin_split_kernel<KS>:  Y (T, N) = X (T, K) W^T [+ bias] with K = 16 KS.
+//     * a wave owns 32 tokens: lane (r = lane & 31, h = lane >> 5) keeps X[token r][16 s + 8 h + j], j < 8, of every
+//       k-step s in registers (f32) for the whole kernel -- X is read from HBM once -- and splits the eight values of
+//       a k-step into bf16 B fragments right before they are used (44 VALU instructions hidden under 24 MFMAs);
+//     * the weights are split ONCE by the pack kernel into fragment-ordered bf16 planes
+//       [chunk of 128 outputs][k-step][32-row block][plane h/m/l][lane][8 bf16]; a workgroup (4 waves, 128 tokens)
+//       streams them through a double-buffered LDS tile (2 k-steps = 24 KB per buffer, one barrier per 48 MFMAs),
+//       global -> registers -> LDS, the loads of the next tile in flight under the MFMAs of the current one.
+#include "pda_common.h"
+
+namespace pda {
+
+typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int GS_MAX_N = 2048;                   // widest output (bias staged in LDS)
+constexpr int GS_KSTEP = 12 * 64;                // uint4 per k-step of a 128-output chunk (4 row blocks x 3 planes x 64 lanes)
+
+// One 16-byte LDS-DMA per lane: global (per-lane address) -> LDS (wave-uniform byte address in M0 + lane * 16), no VGPR
+// in between.  Written as asm so that hipcc does not know about the pending LDS write: with the builtin it puts
+// s_waitcnt vmcnt(0) in front of every ds_read of the ring, which serialises the DMA of tile t + 2 with the MFMAs of
+// tile t.  The waits are the counted ones in the kernel.
+__device__ __forceinline__ void glds16(const uint4* g, uint32_t lds_wave_base) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(g), "s"(lds_wave_base) : "memory");
+}
+
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = f32x2_to_bf16x2(x0, x1);
+    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
+    m = f32x2_to_bf16x2(r0, r1);
+    l = f32x2_to_bf16x2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
+}
+
+// W (rows, cols) row-major (trans: the source holds W^T, (cols, rows) row-major) -> fragment-ordered planes.
+__global__ void split_pack_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf, int rows, int cols, int KS,
+                                  int chunks, int trans) {
+    const int64_t total = (int64_t)chunks * KS * 4 * 64 * 4;       // one thread per (chunk, s, rb, lane, pair)
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
+        const int pr = (int)(o & 3), lane = (int)((o >> 2) & 63);
+        int64_t rest = o >> 8;
+        const int rb = (int)(rest & 3); rest >>= 2;
+        const int s = (int)(rest % KS), c = (int)(rest / KS);
+        const int row = c * 128 + rb * 32 + (lane & 31);
+        const int k = 16 * s + 8 * (lane >> 5) + 2 * pr;
+        float v[2];
+        for (int e = 0; e < 2; ++e)
+            v[e] = (row < rows && k + e < cols) ? (trans ? w[(size_t)(k + e) * rows + row] : w[(size_t)row * cols + k + e]) : 0.f;
+        uint32_t h, m, l;
+        split2(v[0], v[1], h, m, l);
+        const size_t base = ((((size_t)c * KS + s) * 4 + rb) * 3) * 256 + (size_t)lane * 4 + pr;    // uint32 units
+        wf[base] = h; wf[base + 256] = m; wf[base + 512] = l;
+    }
+}
+
+struct LinSplitParams {
+    const float* x;         // (T, K) row-major
+    const uint4* wf;        // packed planes
+    const float* bias;      // (N) or null
+    float* y;               // (T, N) row-major
+    int64_t tokens;
+    int k, n_out, chunks, relu;
+    unsigned long long* dbg;    // GS_PROFILE builds: per-workgroup phase clocks
+};
+#ifdef GS_PROFILE
+#define GS_MARK(i) do { if (tid == 0) p.dbg[(size_t)blockIdx.x * 16 + (i)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define GS_MARK(i) do {} while (0)
+#endif
+
+template <int KS>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1)))
+void lin_split_kernel(const LinSplitParams p) {
+    constexpr int G = KS % 4 == 0 ? 4 : 2;       // k-steps per LDS tile: 96 or 48 MFMAs between barriers
+    constexpr int TILE = G * GS_KSTEP;           // uint4 per tile (48 KB / 24 KB)
+    constexpr int NG = KS / G;                   // tiles per chunk
+    constexpr int NLD = TILE / 256;              // LDS-DMA instructions per wave per tile
+    __shared__ uint4 ring[3 * TILE];             // tile t lives in slot t % 3: one being read, one landed, one in flight
+    __shared__ float bias_s[GS_MAX_N];           // an ordinary load in the loop would make hipcc drain the DMA (vmcnt(0))
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, j = lane & 31;
+    const int64_t tok0 = ((int64_t)blockIdx.x * 4 + w) * 32;
+    const int64_t tk = tok0 + j < p.tokens ? tok0 + j : p.tokens - 1;
+    const uint4* src = p.wf + tid;
+    const int ntiles = p.chunks * NG;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring + w * 1024;
+    auto issue = [&](int t, int slot) {          // tile t -> ring slot (the tile behind the last is the last again)
+        const uint4* g = src + (size_t)(t < ntiles ? t : ntiles - 1) * TILE;
+        const uint32_t l = ring_base + slot * (TILE * 16);
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) glds16(g + 256 * i, l + 4096 * i);
+    };
+    static_assert(NLD <= G * 4, "one DMA instruction per MFMA group at most");
+    GS_MARK(0);
+    float x[KS * 8];
+    {
+        const float* row = p.x + tk * p.k + 8 * h;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const float4 a = *reinterpret_cast<const float4*>(row + 16 * s), b = *reinterpret_cast<const float4*>(row + 16 * s + 4);
+            x[8 * s] = a.x; x[8 * s + 1] = a.y; x[8 * s + 2] = a.z; x[8 * s + 3] = a.w;
+            x[8 * s + 4] = b.x; x[8 * s + 5] = b.y; x[8 * s + 6] = b.z; x[8 * s + 7] = b.w;
+        }
+    }
+    for (int i = tid; i < p.n_out; i += 256) bias_s[i] = p.bias ? p.bias[i] : 0.f;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row loads: nothing ordinary in flight beside the DMA below
+    GS_MARK(1);
+    issue(0, 0);
+    issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+    __builtin_amdgcn_s_barrier();
+    GS_MARK(2);
+    // rows of a 32x32 tile: token (i & 3) + 8 (i >> 2) + 4 h; column: output feature chunk * 128 + r * 32 + j.
+    // Address = wave-uniform row base (scalar registers) + one per-lane offset: no vector address arithmetic per store.
+    const uint32_t lane_off = (uint32_t)(4 * h * p.n_out + j);
+    const int64_t left = p.tokens - tok0 - 4 * h;
+    const bool whole = tok0 + 32 <= p.tokens;                 // wave-uniform
+    // store number n (0..63) of a finished chunk: row block n / 16, accumulator register n % 16
+    auto store_one = [&](const gs_f32x16 (&res)[4], int chunk, int n) {
+        const int r = n >> 4, i = n & 15, t = (i & 3) + 8 * (i >> 2);
+        float v = res[r][i] + bias_s[chunk * 128 + r * 32 + j];
+        if (p.relu) v = fmaxf(v, 0.f);
+        float* row = p.y + (tok0 + t) * p.n_out + chunk * 128 + r * 32;      // uniform
+        if (whole) row[lane_off] = v;
+        else if (t < left) row[lane_off] = v;
+    };
+    int ti = 0, slot = 0;                        // slot = ti % 3
+    gs_f32x16 done[4];                           // results of the previous chunk, stored under the next chunk's first tile
+    for (int c = 0; c < p.chunks; ++c) {
+        gs_f32x16 acc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[r][i] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g, ++ti, slot = slot == 2 ? 0 : slot + 1) {
+            // The 64 stores of the previous chunk are spread over the MFMA groups of this one: issued as one block,
+            // the four waves (and every CU of the chip, in step) saturate the write path while the matrix pipe idles.
+            if (c == 1 && g == 0) GS_MARK(4);
+            // the DMA of tile ti + 2: one instruction behind each of the first NLD MFMA groups (a block of them in front
+            // cost 57 cycles each with the matrix pipe idle)
+            const uint4* dsrc = src + (size_t)(ti + 2 < ntiles ? ti + 2 : ntiles - 1) * TILE;
+            const uint32_t ddst = ring_base + (slot == 0 ? 2 : slot - 1) * (TILE * 16);
+            if (c == 1 && g == 0) GS_MARK(5);
+            const uint4* buf = ring + slot * TILE + lane;
+            // fragments of (k-step, row block) group q + 1 are read while the six MFMAs of group q run
+            uint4 fa[2][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) fa[0][pl] = buf[pl * 64];
+#pragma unroll
+            for (int sl = 0; sl < G; ++sl) {
+                const int s = g * G + sl;
+                if constexpr (KS > 16) {          // keep the f32 row: split again per chunk instead of 1.5x the registers
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) asm volatile("" : "+v"(x[8 * s + q]));
+                }
+                uint32_t bh[4], bm[4], bl[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) split2(x[8 * s + 2 * q], x[8 * s + 2 * q + 1], bh[q], bm[q], bl[q]);
+                const gs_bf16x8 Xh = __builtin_bit_cast(gs_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+                const gs_bf16x8 Xm = __builtin_bit_cast(gs_bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+                const gs_bf16x8 Xl = __builtin_bit_cast(gs_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = sl * 4 + r;
+                    if (q + 1 < G * 4) {
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) fa[(q + 1) & 1][pl] = buf[((q + 1) * 3 + pl) * 64];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const gs_bf16x8 Wh = __builtin_bit_cast(gs_bf16x8, fa[q & 1][0]);
+                    const gs_bf16x8 Wm = __builtin_bit_cast(gs_bf16x8, fa[q & 1][1]);
+                    const gs_bf16x8 Wl = __builtin_bit_cast(gs_bf16x8, fa[q & 1][2]);
+                    // tokens are the A operand (rows of the tile), output features the B operand: a lane ends up with
+                    // ONE output column of 16 token rows, so a store instruction writes 128 contiguous bytes per row.
+                    // smallest terms first
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xl, Wh, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wl, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wm, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wh, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wm, acc[r], 0, 0, 0);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wh, acc[r], 0, 0, 0);
+                    if (q < NLD) glds16(dsrc + 256 * q, ddst + 4096 * q);
+                    if (c > 0) {
+                        constexpr int GROUPS = KS * 4;                 // MFMA groups per chunk
+                        const int gq = g * G * 4 + q;
+#pragma unroll
+                        for (int n = gq * 64 / GROUPS; n < (gq + 1) * 64 / GROUPS; ++n) store_one(done, c - 1, n);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // tile ti + 1 has landed (ti + 2 may still be in flight); everyone is done reading tile ti
+            if (c == 1 && g == 0) GS_MARK(6);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
+            if (c == 1 && g == 0) GS_MARK(7);
+            __builtin_amdgcn_s_barrier();
+            if (c == 1 && g == 0) GS_MARK(8);
+            if (c == 0 && g == NG - 1) GS_MARK(3);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) done[r] = acc[r];
+    }
+    GS_MARK(9);
+#pragma unroll
+    for (int n = 0; n < 64; ++n) store_one(done, p.chunks - 1, n);
+    GS_MARK(10);
+}
+
+}  // namespace pda
+
+PDA_API int64_t pda_linear_split_packed_bytes(int n_out, int k) {
+    if (n_out <= 0 || k <= 0) return 0;
+    return (int64_t)pda::divup(n_out, 128) * pda::divup(k, 32) * 2 * 12 * 64 * 16;
+}
+
+PDA_API int pda_linear_split_pack(const float* w, void* wf, int n_out, int k, int transposed_source, pda_stream_t stream) {
+    PDA_REQUIRE(w && wf && n_out > 0 && k > 0, "pda_linear_split_pack: bad argument");
+    const int chunks = pda::divup(n_out, 128), KS = pda::divup(k, 32) * 2;
+    const int64_t total = (int64_t)chunks * KS * 4 * 64 * 4;
+    const int blocks = (int)(pda::divup64(total, 256) < 2048 ? pda::divup64(total, 256) : 2048);
+    hipLaunchKernelGGL(pda::split_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint32_t*)wf, n_out, k, KS,
+                       chunks, transposed_source);
+    return pda::check_launch("pda_linear_split_pack");
+}
+
+PDA_API int pda_linear_split(const float* x, const void* wf, const float* bias, float* y, int64_t tokens, int k, int n_out,
+                             int relu, pda_stream_t stream) {
+    PDA_REQUIRE(tokens >= 0 && k > 0 && n_out > 0, "pda_linear_split: bad size");
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(x && wf && y && (((uintptr_t)x | (uintptr_t)wf | (uintptr_t)y | (uintptr_t)bias) & 15) == 0,
+                "pda_linear_split: null or misaligned pointer");
+    if (k % 32 != 0 || k > 512 || n_out % 128 != 0 || n_out > pda::GS_MAX_N) {
+        pda::set_error("pda_linear_split: no kernel built for K=%d, N=%d (K a multiple of 32 <= 512, N a multiple of 128 <= 2048)", k, n_out);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::LinSplitParams p{};
+    p.x = x; p.wf = (const uint4*)wf; p.bias = bias; p.y = y; p.tokens = tokens; p.k = k; p.n_out = n_out; p.chunks = n_out / 128;
+    p.relu = relu;
+#ifdef GS_PROFILE
+    p.dbg = (unsigned long long*)bias; p.bias = nullptr;
+#endif
+    const dim3 grid((unsigned)pda::divup64(tokens, 128)), block(256);
+    const hipStream_t s = (hipStream_t)stream;
+    switch (k / 16) {
+#define PDA_GS_CASE(KS) case KS: hipLaunchKernelGGL((pda::lin_split_kernel<KS>), grid, block, 0, s, p); break
+        PDA_GS_CASE(2); PDA_GS_CASE(4); PDA_GS_CASE(6); PDA_GS_CASE(8); PDA_GS_CASE(12); PDA_GS_CASE(16); PDA_GS_CASE(24); PDA_GS_CASE(32);
+#undef PDA_GS_CASE
+        default:
+            pda::set_error("pda_linear_split: no kernel built for K=%d", k);
+            return PDA_ERR_UNSUPPORTED;
+    }
+    return pda::check_launch("pda_linear_split");
+}

@@ -33,6 +33,40 @@ class _HeadLoss(nn.Module):
         return (loss,) + tuple(tb[k] for k in self.keys)
 
 
+class _TailLoss(nn.Module):
+    """Backbone layers i0.. (the ones behind the last host read of a token count: static shapes) + IASSD_Head.forward +
+    get_loss as a function of TENSORS only.  Arguments: xyz and features of layer i0's input, the scene index per point,
+    gt_boxes, [the class scores layer i0-1 left], the non-empty sa_ins_preds of the layers in front, their encoder_coords.
+    Only the layers it runs are registered as sub-modules (so only their parameters become graph inputs)."""
+
+    def __init__(self, backbone, head, i0, batch_size, has_cls, sa_slots):
+        super().__init__()
+        self.layers, self.head = nn.ModuleList(backbone.SA_modules[i0:]), head
+        self._bb = (backbone,)          # in a tuple: not a registered sub-module
+        self.i0, self.batch_size, self.has_cls, self.sa_slots = i0, batch_size, has_cls, list(sa_slots)
+        self.keys = None
+
+    def forward(self, xyz, feats, bidx, gt_boxes, *rest):
+        bb, i0 = self._bb[0], self.i0
+        rest = list(rest)
+        cls_pred = rest.pop(0) if self.has_cls else None
+        n_sa = sum(self.sa_slots)
+        it = iter(rest[:n_sa])
+        st = dict(batch_size=self.batch_size, encoder_xyz=[None] * i0 + [xyz], encoder_features=[None] * i0 + [feats],
+                  sa_ins_preds=[next(it) if has else [] for has in self.sa_slots], sample_ids=[[] for _ in range(i0)],
+                  encoder_coords=rest[n_sa:], bidx=bidx, li_cls_pred=cls_pred, presampled={})
+        bd = {'batch_size': self.batch_size, 'gt_boxes': gt_boxes}
+        with bb.bn_counters():
+            for i in range(i0, len(bb.SA_modules)):
+                bb._run_layer(i, st)
+            bb._finish(bd, st)
+            self.head(bd)
+        loss, tb = self.head.get_loss()
+        if self.keys is None:
+            self.keys = [k for k, v in tb.items() if isinstance(v, torch.Tensor)]
+        return (loss,) + tuple(tb[k] for k in self.keys)
+
+
 class IASSD(nn.Module):
     def __init__(self, model_cfg, num_class, num_point_features):
         super().__init__()
@@ -46,7 +80,11 @@ class IASSD(nn.Module):
         # Off by default: capture runs a few warm-up iterations of the head first (its BatchNorm running statistics
         # move, `num_batches_tracked` is not advanced by replays), so exact-trajectory tests use the eager form.
         self.graph_head = False
+        # graph_tail: the same from the first backbone layer behind the last unique-token plan (backbone.
+        # first_static_tail_layer: ONCE layers 3, 4, 5) -- everything after the step's last host read is two replays.
+        self.graph_tail = False
         self._graphed = None
+        self._graphed_tail = None
 
     def _head_loss_graphed(self, bd):
         sa = bd['sa_ins_preds']
@@ -56,20 +94,58 @@ class IASSD(nn.Module):
         key = tuple((tuple(a.shape), a.requires_grad) for a in args)
         if self._graphed is None or self._graphed[0] != key:
             fn = _HeadLoss(self.point_head, bd['batch_size'], [isinstance(p, torch.Tensor) for p in sa], len(bd['encoder_coords']))
-            sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
-            # the warm-up iterations run on a side stream: AccumulateGrad nodes created there trigger a (harmless)
-            # stream-mismatch warning on the first real backward; silence it for the capture only
-            warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if warn is not None:
-                warn(False)
-            graphed = torch.cuda.make_graphed_callables(fn, sample, allow_unused_input=True)
+            graphed = self._capture(fn, args)
             self._graphed = (key, graphed, fn)
         _, graphed, fn = self._graphed
         out = graphed(*args)
         return out[0], dict(zip(fn.keys, (o.detach() for o in out[1:])))
 
+    @staticmethod
+    def _capture(fn, args):
+        sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+        # the warm-up iterations run on a side stream: AccumulateGrad nodes created there trigger a (harmless)
+        # stream-mismatch warning on the first real backward; silence it for the capture only
+        warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if warn is not None:
+            warn(False)
+        return torch.cuda.make_graphed_callables(fn, sample, allow_unused_input=True)
+
+    def tail_start(self):
+        """First layer of the graphed tail, or None when the layers behind it reach back in front of it."""
+        bb = self.backbone_3d
+        i0, n = bb.first_static_tail_layer(), len(bb.SA_modules)
+        if not 0 < i0 < n:
+            return None
+        for i in range(i0, n):
+            if bb.layer_inputs[i] < i0 or (bb.layer_types[i] == 'SA_Layer' and -1 < bb.ctr_idx_list[i] < i0):
+                return None
+        return i0
+
+    def _forward_graphed_tail(self, batch_dict, i0):
+        bb = self.backbone_3d
+        with bb.bn_counters():
+            st = bb._begin(batch_dict)
+            for i in range(i0):
+                bb._run_layer(i, st)
+        sa, cls_pred = st['sa_ins_preds'], st['li_cls_pred']
+        args = [st['encoder_xyz'][i0], st['encoder_features'][i0], st['bidx'], batch_dict['gt_boxes']]
+        args += ([cls_pred] if cls_pred is not None else []) + [p for p in sa if isinstance(p, torch.Tensor)] + list(st['encoder_coords'])
+        args = [a.contiguous() for a in args]
+        key = (i0,) + tuple((tuple(a.shape), a.requires_grad) for a in args)
+        if self._graphed_tail is None or self._graphed_tail[0] != key:
+            fn = _TailLoss(bb, self.point_head, i0, st['batch_size'], cls_pred is not None, [isinstance(p, torch.Tensor) for p in sa])
+            self._graphed_tail = (key, self._capture(fn, args), fn)
+        _, graphed, fn = self._graphed_tail
+        out = graphed(*args)
+        return out[0], dict(zip(fn.keys, (o.detach() for o in out[1:])))
+
     def forward(self, batch_dict):
-        if self.training and self.graph_head and torch.is_grad_enabled():
+        if self.training and self.graph_tail and torch.is_grad_enabled():
+            i0 = self.tail_start()
+            if i0 is not None:
+                loss, tb_dict = self._forward_graphed_tail(batch_dict, i0)
+                return {'loss': loss}, tb_dict, {}
+        if self.training and (self.graph_head or self.graph_tail) and torch.is_grad_enabled():
             batch_dict = self.backbone_3d(batch_dict)
             loss, tb_dict = self._head_loss_graphed(batch_dict)
             return {'loss': loss}, tb_dict, {}

@@ -577,6 +577,25 @@ def linear_cols(x, wf, y, tokens, k, n_out):
     return 1
 
 
+# ---- f32 GEMM on the bf16 matrix cores, operands split into three bf16 terms (csrc/gemm_split.hip) -----------------
+def linear_split_pack(w, n_out, k, transposed_source=False):
+    lib = _lib.load()
+    wf = torch.empty((int(lib.pda_linear_split_packed_bytes(int(n_out), int(k))),), dtype=torch.uint8, device=w.device)
+    _numel_ok(w, n_out * k, "w")
+    _call("pda_linear_split_pack", w, _chk(w, "w", F32), _chk(wf, "wf", torch.uint8), n_out, k, 1 if transposed_source else 0)
+    return wf
+
+
+def linear_split(x, wf, bias, y, tokens, k, n_out, relu=False):
+    _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
+    _numel_ok(wf, int(_lib.load().pda_linear_split_packed_bytes(int(n_out), int(k))), "wf")
+    if bias is not None:
+        _numel_ok(bias, n_out, "bias")
+    _call("pda_linear_split", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), None if bias is None else _chk(bias, "bias", F32),
+          _chk(y, "y", F32), tokens, k, n_out, 1 if relu else 0)
+    return 1
+
+
 def sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, b, n, m, c, nsample, n_out):
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(feats_pm, b * n * c, "feats_pm")
     _numel_ok(idx, b * m * nsample, "idx"); _numel_ok(y, b * m * nsample * n_out, "y")

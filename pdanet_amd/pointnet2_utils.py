@@ -527,6 +527,8 @@ def _b16p(p):
     optimizer step, load_state_dict) -- a step uses each weight in 2-3 GEMMs, and each cast is a launch."""
     if p.dtype == torch.bfloat16:
         return p
+    if p.is_cuda and torch.cuda.is_current_stream_capturing():
+        return p.detach().to(torch.bfloat16)        # the cast belongs INSIDE the graph: a replay must see the new weights
     key = id(p)
     stamp = (p._version, p.data_ptr(), _lib.PARAM_EPOCH[0])
     hit = _B16_PARAMS.get(key)
@@ -803,6 +805,21 @@ def _sa_timed(flops, fn):
     ev.append((e0, e1, flops))
 
 
+# SPLIT_GEMM: the contractions of LinearColsMFMA run on the bf16 matrix cores with three-term bf16 operands
+# (csrc/gemm_split.hip: f32-grade results, measured 1.3-1.5x the f32 MFMA kernel); False: lin_cols_kernel (f32 MFMA).
+SPLIT_GEMM = os.environ.get("PDA_SPLIT_GEMM", "1") != "0"
+
+
+def _lin_cols(x2, weight, y, T, k, n_out, transposed):
+    """y (T, n_out) = x2 (T, k) W'^T with W' = weight (n_out, k), or weight^T when `transposed` (weight is (k, n_out))."""
+    if SPLIT_GEMM:
+        wf = pointnet2.linear_split_pack(weight, n_out, k, transposed_source=transposed)
+        _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out))
+    else:
+        wf = pointnet2.linear_cols_pack(weight, n_out, k, transposed_source=transposed)
+        _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(x2, wf, y, T, k, n_out))
+
+
 class LinearColsMFMA(Function):
     """y = x W^T (no bias) over the last dim of x (..., K): forward and input gradient on lin_cols_kernel, weight
     gradient on csrc/wgrad.hip (or the library below its break-even)."""
@@ -819,8 +836,7 @@ class LinearColsMFMA(Function):
         x2 = x.contiguous().view(-1, k)
         T = x2.shape[0]
         y = torch.empty((T, n_out), dtype=torch.float32, device=x.device)
-        wf = pointnet2.linear_cols_pack(weight.contiguous(), n_out, k)
-        _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(x2, wf, y, T, k, n_out))
+        _lin_cols(x2, weight.contiguous(), y, T, k, n_out, False)
         ctx.save_for_backward(x2, weight)
         ctx.x_shape = x.shape
         return y.view(*x.shape[:-1], n_out)
@@ -836,8 +852,7 @@ class LinearColsMFMA(Function):
             if n_out in (256, 512) and k % 128 == 0:
                 gx = torch.empty((T, k), dtype=torch.float32, device=g2.device)
                 # dX = dY W: the same kernel with the weights packed from the transposed source
-                wft = pointnet2.linear_cols_pack(weight.contiguous(), k, n_out, transposed_source=True)
-                _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(g2, wft, gx, T, n_out, k))
+                _lin_cols(g2, weight.contiguous(), gx, T, n_out, k, True)
             else:
                 gx = g2.mm(weight)
             gx = gx.view(ctx.x_shape)

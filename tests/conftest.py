@@ -22,7 +22,7 @@ _ORDER = [
     "test_iou3d_nms",
     "test_golden_composition", "test_iassd_head", "test_optimization",
     "test_fused_sa_mlp", "test_sa_mlp_train", "test_group_attention", "test_layer_norm", "test_bn_relu",
-    "test_linear_wgrad", "test_densitynet", "test_ragged_tokens",
+    "test_linear_wgrad", "test_gemm_split", "test_densitynet", "test_ragged_tokens",
     "test_parallel_gloo", "test_bench_contract",
     "test_detector_train",
 ]

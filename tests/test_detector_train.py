@@ -80,18 +80,23 @@ def test_training_learns_over_40_iterations(cfg, dataset):
     assert float(np.mean(losses[-10:])) < float(np.mean(losses[:10])), losses
 
 
-def test_graphed_head_equals_eager_head():
-    """detector.IASSD.graph_head: the head + losses replayed as hipGraphs (forward and backward) give the eager
-    iteration: same loss, same clipped-gradient norm, same parameter update; log values come back as tensors."""
+@pytest.mark.parametrize("segment", ["head", "tail"])
+def test_graphed_head_equals_eager_head(segment):
+    """detector.IASSD.graph_head / graph_tail: the head + losses (tail: and the backbone layers behind the last
+    unique-token plan) replayed as hipGraphs (forward and backward) give the eager iteration: same loss, same
+    clipped-gradient norm, same parameter update; log values come back as tensors."""
     res = {}
     for graphed in (False, True):
         model, opt, sched, bd = _setup("once_pda_ssd.yaml", "once")
-        model.graph_head = graphed
+        setattr(model, "graph_" + segment, graphed)
+        if segment == "tail":
+            assert model.tail_start() == 3
         out = []
         for it in range(2):      # the second iteration replays the captured graphs
             ret, tb = _iteration(model, opt, sched, bd, it)
             if it == 0:
-                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters() if "point_head" in n}
+                grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()
+                         if p.grad is not None and ("point_head" in n or segment == "tail")}
             opt.step()
             out.append((float(ret['loss'].detach()), float(opt.total_norm), {k: float(v) for k, v in tb.items()}))
         res[graphed] = (out, grads)
@@ -102,8 +107,9 @@ def test_graphed_head_equals_eager_head():
     for k in eo[0][2]:
         assert go[0][2][k] == pytest.approx(eo[0][2][k], rel=1e-4, abs=1e-6), k
     assert set(eg) == set(gg) and len(gg) >= 12
-    for n in eg:
-        assert (eg[n] - gg[n]).abs().max().item() <= 1e-4 * max(1e-3, eg[n].abs().max().item()), n
+    gmax = max(float(v.abs().max()) for v in eg.values())
+    for n in eg:       # (a conv bias in front of a BatchNorm has an exactly-zero gradient: rounding noise of the largest one)
+        assert (eg[n] - gg[n]).abs().max().item() <= 1e-4 * max(1e-3, eg[n].abs().max().item()) + 1e-6 * gmax, n
     # after one (Adam, sign-like) step the two runs are different trajectories in the last bits; the replayed iteration
     # must still be the same computation: finite and close
     assert np.isfinite(go[1][0]) and go[1][0] == pytest.approx(eo[1][0], rel=0.2)
