@@ -135,16 +135,16 @@ class KernelTimers:
         t = self._mean_s([e[:2] for e in self.fps_events if e[2:] == (b, n, m)])
         alg = fps_algorithmic_bytes(n, m) * b
         ach = alg / t / 1e9
-        kern = "fps_pruned_kernel" if 2048 <= n <= 65536 else "fps_reg_kernel"
+        kern = "fps_chain_kernel" if 2048 <= n <= 16384 else ("fps_pruned_kernel" if 24576 < n <= 65536 else "fps_reg_kernel")
         return {"kernel": "%s (FPS %d->%d, %d scenes/launch)" % (kern, n, m, b), "bound": "hbm", "achieved": ach,
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("pda::fps_pruned_kernel FPS %d->%d b%d" % (n, m, b), ["fps.hip"]),
+                "traffic": pmc_traffic("pda::%s FPS %d->%d b%d" % (kern, n, m, b), ["fps.hip"]),
                 "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg,
                 "compulsory_bytes_per_launch": (n * 16 + m * 4) * b,
                 "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene: the specified algorithm with no "
                         "on-chip reuse) / kernel time.  The kernel keeps the scene on chip (exact spatial pruning "
                         "skips no-op updates), so its real HBM traffic is the compulsory N*16+m*4 bytes per scene "
-                        "and it is bound by the latency of m-1 dependent arg-max rounds, not by HBM.  traffic = "
+                        "and it is bound by the latency of the dependent arg-max rounds (fps_chain_kernel: ~3.5 samples per synchronisation), not by HBM.  traffic = "
                         "(2*FETCH_SIZE+WRITE_SIZE) KB per launch from the committed rocprofv3 --pmc passes "
                         "(null when the kernel source changed since the pass)"}
 
@@ -160,7 +160,7 @@ class KernelTimers:
         peak_tests = VALU_LANE_OPS / BALL_QUERY_VALU_PER_TEST
         return {"kernel": "ball query (%s) %dx%d, radii %s, nsample %s, %d scenes/call" % (path, m, n, list(radii), list(nss), b),
                 "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                "traffic": pmc_traffic("pda::ball_query %dx%d r%d b%d" % (m, n, len(radii), b), ["ball_query.hip"]),
+                "traffic": pmc_traffic("pda::ball_query %dx%d r%d b%d" % (m, n, len(radii), b), ["ball_query.hip", "ball_query_cells.hip"]),
                 "avg_launch_ms": t * 1e3, "algorithmic_bytes_per_launch": alg,
                 "distance_tests_per_launch": tests, "tests_per_s": tests / t,
                 "valu_bound_tests_per_s": peak_tests, "valu_frac": tests / t / peak_tests,

@@ -158,7 +158,7 @@ __device__ __forceinline__ void fps_extract(int js, int lstar, const float (&px)
 }
 
 #ifdef PDA_FPS_STATS
-__device__ unsigned long long g_fps_stats[4];  // [0] wave-scans, [1] wave-rounds, [2] hit lanes
+__device__ unsigned long long g_fps_stats[16];  // [0] wave-scans, [1] wave-rounds, [2] hit lanes
 #endif
 
 // Cooperative form (COOP): K workgroups share one scene (16384 < N <= 65536).  Workgroup g owns the
@@ -184,33 +184,19 @@ __device__ int g_fps_spin_limit = FPS_SPIN_LIMIT;
 __device__ unsigned int g_fps_fail[FPS_XBUF_REGIONS * FPS_XBUF_SCENES];   // launch epoch of a timed-out exchange, per scene
 __device__ unsigned long long g_fps_fail_total;                            // workgroups that ever timed out
 
-template <int P, bool COOP>
-__global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __restrict__ xyz_all,
-                                                                  float* __restrict__ temp_all,
-                                                                  int32_t* __restrict__ idx_all, int n_total,
-                                                                  int m, int L, int K, int nb, uint32_t epoch) {
-    constexpr int NS = FPS_THREADS * P;  // sort size (power of two)
-    __shared__ uint32_t skey[NS];
-    __shared__ float red[FPS_WAVES * 6];
-    __shared__ uint2 slots[2][FPS_WAVES];
-    __shared__ float4 cand[2][FPS_WAVES];
-    __shared__ int failflag;
+// Set-up shared by the pruned forms: scene bounding box -> adaptive 18-bit curve key -> bitonic sort in LDS -> lane t takes
+// the P consecutive sorted points t*P .. t*P+P-1 (ordered by tie-break value inside the lane) into registers, with the
+// lane's bounding box and its running maximum.  skey: NS = 1024 * P words, red: FPS_WAVES * 6 floats (LDS).
+template <int P>
+__device__ __forceinline__ void fps_sorted_setup(const float* __restrict__ xyz, const float* __restrict__ temp, int n, int k_lo,
+                                                 int L, uint32_t* skey, float* red, float (&px)[P], float (&py)[P],
+                                                 float (&pz)[P], float (&tp)[P], uint32_t (&kT)[P], int (&kk)[P],
+                                                 float (&blo)[3], float (&bhi)[3], float& lbest, int& bi) {
+    constexpr int NS = FPS_THREADS * P;
     const int t = threadIdx.x;
     const int lane = lane_id();
     const int w = wave_id();
-    const int scene = COOP ? (int)(blockIdx.x % nb) : (int)blockIdx.x;
-    const int g = COOP ? (int)(blockIdx.x / nb) : 0;      // my share of the scene
-    const int nper = COOP ? (n_total + K - 1) / K : n_total;
-    const int k_lo = g * nper;                             // first global index I own
-    const int n = max(0, min(n_total, k_lo + nper) - k_lo);  // points I own (local indices 0..n-1)
-    const float* __restrict__ xyz0 = xyz_all + (size_t)scene * n_total * 3;  // the scene
-    const float* __restrict__ xyz = xyz0 + (size_t)k_lo * 3;                 // my range
-    float* __restrict__ temp = temp_all + (size_t)scene * n_total + k_lo;
-    int32_t* __restrict__ idx = idx_all + (size_t)scene * m;
     const float INF = __builtin_inff();
-    if (t == 0) failflag = 0;
-    const int spin_limit = COOP ? g_fps_spin_limit : 0;
-
     // ---- 1. scene bounding box ---------------------------------------------------------
     float lo[3] = {INF, INF, INF}, hi[3] = {-INF, -INF, -INF};
 #pragma unroll
@@ -294,8 +280,6 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
         }
     }
     // ---- 4. my P consecutive sorted points, ordered by tie-break value inside the lane ------
-    uint32_t kT[P];   // tie-break value (0xffffffff = empty slot)
-    int kk[P];
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         const uint32_t e = skey[t * P + i];
@@ -319,10 +303,9 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
                     kk[i] = sw ? kb : ka; kk[l2] = sw ? ka : kb;
                 }
             }
-    float px[P], py[P], pz[P], tp[P];
-    float blo[3] = {INF, INF, INF}, bhi[3] = {-INF, -INF, -INF};
-    float lbest = -1.f;
-    int bi = 0;
+    blo[0] = blo[1] = blo[2] = INF; bhi[0] = bhi[1] = bhi[2] = -INF;
+    lbest = -1.f;
+    bi = 0;
 #pragma unroll
     for (int i = 0; i < P; ++i) {
         if (kk[i] >= 0) {
@@ -339,6 +322,42 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
         bi = g ? i : bi;
         lbest = g ? tp[i] : lbest;
     }
+
+}
+
+template <int P, bool COOP>
+__global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __restrict__ xyz_all,
+                                                                  float* __restrict__ temp_all,
+                                                                  int32_t* __restrict__ idx_all, int n_total,
+                                                                  int m, int L, int K, int nb, uint32_t epoch) {
+    constexpr int NS = FPS_THREADS * P;  // sort size (power of two)
+    __shared__ uint32_t skey[NS];
+    __shared__ float red[FPS_WAVES * 6];
+    __shared__ uint2 slots[2][FPS_WAVES];
+    __shared__ float4 cand[2][FPS_WAVES];
+    __shared__ int failflag;
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int scene = COOP ? (int)(blockIdx.x % nb) : (int)blockIdx.x;
+    const int g = COOP ? (int)(blockIdx.x / nb) : 0;      // my share of the scene
+    const int nper = COOP ? (n_total + K - 1) / K : n_total;
+    const int k_lo = g * nper;                             // first global index I own
+    const int n = max(0, min(n_total, k_lo + nper) - k_lo);  // points I own (local indices 0..n-1)
+    const float* __restrict__ xyz0 = xyz_all + (size_t)scene * n_total * 3;  // the scene
+    const float* __restrict__ xyz = xyz0 + (size_t)k_lo * 3;                 // my range
+    float* __restrict__ temp = temp_all + (size_t)scene * n_total + k_lo;
+    int32_t* __restrict__ idx = idx_all + (size_t)scene * m;
+    if (t == 0) failflag = 0;
+    const int spin_limit = COOP ? g_fps_spin_limit : 0;
+
+    uint32_t kT[P];   // tie-break value (0xffffffff = empty slot)
+    int kk[P];
+    float px[P], py[P], pz[P], tp[P];
+    float blo[3], bhi[3];
+    float lbest;
+    int bi;
+    fps_sorted_setup<P>(xyz, temp, n, k_lo, L, skey, red, px, py, pz, tp, kT, kk, blo, bhi, lbest, bi);
 
     // wave candidate cache (wave-uniform values)
     float wmax = -1.f, cx = 0.f, cy = 0.f, cz = 0.f;
@@ -494,6 +513,207 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
         if (kk[i] >= 0) temp[kk[i]] = tp[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// fps_chain_kernel<P>: the pruned form with SEVERAL samples per synchronisation (2048 <= N <= 16384).
+//
+// FPS is m-1 dependent rounds, and a round of the pruned kernel is two barriers plus one wave scanning alone
+// (0.91 us).  Most of that dependence is not real: the next sample is the best candidate that the new sample does
+// not reach, and samples are far apart by construction.  Every wave keeps a record {best value, tie-break T, the
+// best point's coordinates, second-best value} of its 1024 points.  After ONE barrier wave 0 walks the 16 records:
+//   * the best VALID record is the next sample if its value is above every bound of the invalid waves;
+//   * taking a sample invalidates its own wave (whose new maximum is bounded by its second-best value) and every
+//     wave whose best point the sample reaches (d < value, the same f32 expression the scan evaluates, so the test
+//     is exact; bound max(second, d));  all other records stay exact -- their points may change, their best cannot.
+// The walk stops at the first candidate it cannot prove (or FPS_CHAIN_MAX); its samples go to LDS, and after the
+// second barrier every wave applies the whole chain to the clusters each sample can reach (the conservative box
+// test of the pruned kernel) and refreshes its record once.  Indices and the final `temp` are bit-identical to the
+// reference: skipped updates are no-ops, accepted samples are proven arg-maxima under the same total order.
+// Host replay on the bench scene (build/fps_chain_sim.py): 3.55 samples per synchronisation.
+constexpr int FPS_CHAIN_MAX = 8;
+
+template <int P>
+__global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __restrict__ xyz_all, float* __restrict__ temp_all,
+                                                                 int32_t* __restrict__ idx_all, int n, int m, int L) {
+    constexpr int NS = FPS_THREADS * P;
+    __shared__ uint32_t skey[NS];
+    __shared__ float red[FPS_WAVES * 6];
+    __shared__ float4 rec_a[FPS_WAVES];     // {value, T, x, y} of the wave's best point
+    __shared__ float4 rec_b[FPS_WAVES];     // {z, second-best value, -, -}
+    __shared__ float4 chain[FPS_CHAIN_MAX]; // {x, y, z, T} of the samples decided at the last synchronisation
+    __shared__ int chain_n;
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int w = wave_id();
+    const float* __restrict__ xyz = xyz_all + (size_t)blockIdx.x * n * 3;
+    float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
+    int32_t* __restrict__ idx = idx_all + (size_t)blockIdx.x * m;
+
+    uint32_t kT[P];
+    int kk[P];
+    float px[P], py[P], pz[P], tp[P];
+    float blo[3], bhi[3];
+    float lbest;
+    int bi;
+    fps_sorted_setup<P>(xyz, temp, n, 0, L, skey, red, px, py, pz, tp, kT, kk, blo, bhi, lbest, bi);
+
+    if (t == 0) {
+        idx[0] = 0;
+        chain[0] = make_float4(xyz[0], xyz[1], xyz[2], 0.f);   // sample 0 = point 0
+        chain_n = 1;
+    }
+    __syncthreads();
+#ifdef PDA_FPS_STATS
+    unsigned long long t_scan = 0, t_dec = 0, t_bar = 0, n_round = 0, n_scanw = 0, t0s;
+#define FPS_T0() t0s = __builtin_readcyclecounter()
+#define FPS_T1(acc) acc += __builtin_readcyclecounter() - t0s
+#else
+#define FPS_T0()
+#define FPS_T1(acc)
+#endif
+    int j = 1;            // indices decided so far
+    int cn = 1;           // samples in the current chain: idx[j - cn .. j - 1]
+    bool dirty = true;    // no record published yet
+    while (true) {
+        // ---- apply the chain: sample c is idx[j - cn + c]; the last index of all, idx[m - 1], is never applied ----
+        const int napply = min(cn, (m - 1) - (j - cn));
+        bool scanned = dirty;
+        FPS_T0();
+        for (int c = 0; c < napply; ++c) {
+            const float4 s4 = chain[c];      // same address in every lane
+            const float ex = fmaxf(fmaxf(blo[0] - s4.x, s4.x - bhi[0]), 0.f);
+            const float ey = fmaxf(fmaxf(blo[1] - s4.y, s4.y - bhi[1]), 0.f);
+            const float ez = fmaxf(fmaxf(blo[2] - s4.z, s4.z - bhi[2]), 0.f);
+            const float dbox = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+            const bool hit = dbox * 0.9999f < lbest;     // lbest of the last refresh: an upper bound, still conservative
+            if (__ballot(hit) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) tp[i] = fminf(sqdist3(px[i], py[i], pz[i], s4.x, s4.y, s4.z), tp[i]);   // (x2 - x1), :133
+                scanned = true;
+            }
+        }
+        if (scanned) {
+            // lane: best slot (lower slot wins ties: slots are in tie-break order) and second-best VALUE
+            float bv[P], sv[P];
+            int bx[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) { bv[i] = tp[i]; bx[i] = i; sv[i] = -1.f; }
+#pragma unroll
+            for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+                for (int i = 0; i + st < P; i += 2 * st) {
+                    const bool g = bv[i + st] > bv[i];
+                    sv[i] = fmaxf(fmaxf(sv[i], sv[i + st]), fminf(bv[i], bv[i + st]));
+                    bx[i] = g ? bx[i + st] : bx[i];
+                    bv[i] = fmaxf(bv[i], bv[i + st]);
+                }
+            lbest = bv[0]; bi = bx[0];
+            const float lsec = sv[0];
+            const float wmax = wave_max_f32(lbest);
+            const unsigned long long eq = __ballot(lbest == wmax);
+            int lstar;
+            if (__builtin_popcountll(eq) == 1) {
+                lstar = (int)__builtin_ctzll(eq);
+            } else {
+                uint32_t myT = 0xffffffffu;
+#pragma unroll
+                for (int i = 0; i < P; ++i) myT = (bi == i) ? kT[i] : myT;
+                const uint32_t tmin = wave_min_u32(lbest == wmax ? myT : 0xffffffffu);
+                const unsigned long long eq2 = __ballot(lbest == wmax && myT == tmin);
+                lstar = (int)__builtin_ctzll(eq2 | (1ull << 63));
+            }
+            lstar = __builtin_amdgcn_readfirstlane(lstar);
+            const int js = __builtin_amdgcn_readlane(bi, lstar);
+            float cx, cy, cz;
+            uint32_t wT;
+            fps_extract<0, P>(js, lstar, px, py, pz, kT, cx, cy, cz, wT);
+            // second-best value of the wave (as a multiset: a tie at the maximum makes it the maximum)
+            const float wsec = wave_max_f32(lane == lstar ? lsec : lbest);
+            if (lane == 0) {
+                rec_a[w] = make_float4(wmax, __builtin_bit_cast(float, wT), cx, cy);
+                rec_b[w] = make_float4(cz, wsec, 0.f, 0.f);
+            }
+            dirty = false;
+#ifdef PDA_FPS_STATS
+            n_scanw++;
+#endif
+        }
+        FPS_T1(t_scan);
+        if (j >= m) break;
+        FPS_T0();
+        lds_barrier();
+        FPS_T1(t_bar);
+        FPS_T0();
+        if (w == 0) {
+            // ---- the walk over the 16 records (lanes 0..15); an invalid record carries value -1 ----
+            float val = -1.f, rx = 0.f, ry = 0.f, rz = 0.f, sec = -1.f;
+            uint32_t rT = 0xffffffffu;
+            if (lane < FPS_WAVES) {
+                const float4 a = rec_a[lane], b = rec_b[lane];
+                val = a.x; rT = __builtin_bit_cast(uint32_t, a.y); rx = a.z; ry = a.w; rz = b.x; sec = b.y;
+            }
+            float maxbound = -1.f;
+            float ox = 0.f, oy = 0.f, oz = 0.f;     // lane c collects sample c: one LDS write and one index store at the end
+            uint32_t oT = 0u;
+            const int rem = min(FPS_CHAIN_MAX, m - j);
+            int c = 0;
+            while (c < rem) {
+                const float cv = row0_max_f32(val);
+                if (cv < 0.f || maxbound >= cv) break;      // nothing valid left / an invalidated wave may hold more
+                const unsigned long long eq = __ballot(val == cv);
+                uint32_t cT;
+                int wl;
+                if (__builtin_popcountll(eq) == 1) {
+                    wl = (int)__builtin_ctzll(eq);
+                    cT = (uint32_t)__builtin_amdgcn_readlane((int)rT, wl);
+                } else {
+                    cT = row0_min_u32(val == cv ? rT : 0xffffffffu);
+                    wl = (int)__builtin_ctzll(__ballot(val == cv && rT == cT) | (1ull << 63)) & (FPS_WAVES - 1);
+                }
+                const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), wl));
+                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), wl));
+                const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rz), wl));
+                const float ssec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sec), wl));
+                const bool mine = lane == c;
+                ox = mine ? sx : ox; oy = mine ? sy : oy; oz = mine ? sz : oz; oT = mine ? cT : oT;
+                // which other records does this sample invalidate?  Exactly those whose best point it reaches
+                // (an invalid record has value -1: d >= 0 never reaches it again).
+                const float d = sqdist3(rx, ry, rz, sx, sy, sz);
+                const bool own = lane == wl;
+                const bool reach = d < val && !own;
+                maxbound = fmaxf(maxbound, ssec);
+                if (__ballot(reach) != 0ull) maxbound = fmaxf(maxbound, row0_max_f32(reach ? fmaxf(sec, d) : -1.f));
+                val = (reach || own) ? -1.f : val;
+                ++c;
+            }
+            if (lane < c) {
+                chain[lane] = make_float4(ox, oy, oz, __builtin_bit_cast(float, oT));
+                idx[j + lane] = (int)fps_tiebreak_decode(oT, L);
+            }
+            if (lane == 0) chain_n = c;
+        }
+        FPS_T1(t_dec);
+#ifdef PDA_FPS_STATS
+        n_round++;
+#endif
+        FPS_T0();
+        lds_barrier();
+        FPS_T1(t_bar);
+        cn = __builtin_amdgcn_readfirstlane(chain_n);
+        j += cn;
+    }
+#ifdef PDA_FPS_STATS
+    if (lane == 0 && blockIdx.x == 0) {
+        atomicAdd(&g_fps_stats[4], n_round); atomicAdd(&g_fps_stats[5], n_scanw);
+        atomicMax(&g_fps_stats[6], t_scan); atomicAdd(&g_fps_stats[7], t_scan);
+        if (w == 0) { atomicAdd(&g_fps_stats[8], t_dec); atomicAdd(&g_fps_stats[9], t_bar); }
+        if (w == 5) atomicAdd(&g_fps_stats[10], t_bar);
+    }
+#endif
+#pragma unroll
+    for (int i = 0; i < P; ++i)
+        if (kk[i] >= 0) temp[kk[i]] = tp[i];
+}
+
 template <bool WITH_DIST>
 __device__ __forceinline__ void fps_stream_scene(const float* __restrict__ data, float* __restrict__ temp,
                                                  int32_t* __restrict__ idx, int n, int m, int L, uint2 (*slots)[FPS_WAVES]) {
@@ -619,6 +839,14 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
     }
     const int P = divup(n, FPS_THREADS);
     static const int no_prune = getenv("PDA_FPS_NO_PRUNE") ? atoi(getenv("PDA_FPS_NO_PRUNE")) : 0;
+    static const int no_chain = getenv("PDA_FPS_NO_CHAIN") ? atoi(getenv("PDA_FPS_NO_CHAIN")) : 0;
+    if (!no_prune && !no_chain && n >= 2048 && n <= 16384 && m > 2) {
+        if (P <= 2) hipLaunchKernelGGL((fps_chain_kernel<2>), grid, block, 0, stream, data, temp, idx, n, m, L);
+        else if (P <= 4) hipLaunchKernelGGL((fps_chain_kernel<4>), grid, block, 0, stream, data, temp, idx, n, m, L);
+        else if (P <= 8) hipLaunchKernelGGL((fps_chain_kernel<8>), grid, block, 0, stream, data, temp, idx, n, m, L);
+        else hipLaunchKernelGGL((fps_chain_kernel<16>), grid, block, 0, stream, data, temp, idx, n, m, L);
+        return check_launch(what);
+    }
     if (!no_prune && n >= 2048 && n <= 16384 && m > 2) {
         if (P <= 2) hipLaunchKernelGGL((fps_pruned_kernel<2, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
         else if (P <= 4) hipLaunchKernelGGL((fps_pruned_kernel<4, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
@@ -665,8 +893,8 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
 
 #ifdef PDA_FPS_STATS
 PDA_API int pda_debug_fps_stats(unsigned long long* out, int reset) {
-    hipMemcpyFromSymbol(out, HIP_SYMBOL(pda::g_fps_stats), sizeof(unsigned long long) * 4);
-    if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(pda::g_fps_stats), z, sizeof(z)); }
+    (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(pda::g_fps_stats), sizeof(unsigned long long) * 16);
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(pda::g_fps_stats), z, sizeof(z)); }
     return 0;
 }
 #endif

@@ -74,6 +74,34 @@ def test_fps_exact_ties_lattice(ext, oracle):
         assert np.array_equal(temp_o, temp_d)
 
 
+@pytest.mark.parametrize("case", ["select_all", "duplicates", "lattice_16k", "two_clusters", "line", "m3"])
+def test_fps_chain_kernel_edge_cases(ext, oracle, case):
+    """fps_chain_kernel (2048 <= n <= 16384) decides several samples per synchronisation; the cases where its proofs are
+    tight: every point selected (values fall to exact zeros), duplicated points (d = 0 reaches records of equal
+    coordinates), dense integer lattices (ties in value between waves, ties between best and second-best), two far
+    clusters (long chains alternate between them), collinear points (every sample reaches its neighbours' records)."""
+    rng = np.random.default_rng(11)
+    if case == "select_all":
+        xyz, m = cloud(2, 2048, seed=1), 2048
+    elif case == "duplicates":
+        base = rng.normal(size=(1, 300, 3)).astype(np.float32)
+        xyz, m = np.ascontiguousarray(np.tile(base, (1, 10, 1))[:, rng.permutation(3000)]), 1200   # every point ten times
+    elif case == "lattice_16k":
+        xyz, m = rng.integers(0, 12, size=(1, 16384, 3)).astype(np.float32), 3000                   # 1728 distinct sites
+    elif case == "two_clusters":
+        xyz = rng.normal(size=(1, 8192, 3)).astype(np.float32)
+        xyz[0, ::2] += np.float32(1000.0)
+        m = 2500
+    elif case == "line":
+        xyz = np.zeros((1, 4096, 3), np.float32); xyz[0, :, 0] = rng.permutation(4096).astype(np.float32) * 0.25
+        m = 1500
+    else:
+        xyz, m = cloud(1, 16384, seed=3), 3
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+    assert np.array_equal(idx_o, idx_d)
+    assert np.array_equal(temp_o, temp_d)
+
+
 def test_fps_known_answers_on_gpu(ext):
     xyz = np.zeros((1, 8, 3), np.float32)
     xyz[0, :, 0] = np.arange(8)

@@ -33,7 +33,7 @@ traffic = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
                    "<target> 5; raw pda:: rows next to this file.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 per operator call "
                    "(gfx950: FETCH_SIZE counts half of wide coalesced reads).",
            "csrc_sha1": {f: sha(f) for f in ("fps.hip", "ball_query.hip", "ball_query_cells.hip", "wgrad.hip")}, "kernels": {}}
-for target, key in (("fps", "pda::fps_pruned_kernel FPS 16384->4096 b2"), ("ball_query", "pda::ball_query 16384x16384 r2 b2"),
+for target, key in (("fps", "pda::fps_chain_kernel FPS 16384->4096 b2"), ("ball_query", "pda::ball_query 16384x16384 r2 b2"),
                     ("wgrad", "pda::wgrad_kernel dW(512x512) over 131072 tokens")):
     f, fk = per_call(os.path.join(dst, "fetch_size_%s.csv" % target), "FETCH_SIZE", CALLS)
     w, wk = per_call(os.path.join(dst, "write_size_%s.csv" % target), "WRITE_SIZE", CALLS)

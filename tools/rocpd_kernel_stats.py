@@ -14,7 +14,7 @@ import sys
 
 def main():
     db, steps = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 10
-    marker = sys.argv[3] if len(sys.argv) > 3 else "fps_pruned"
+    marker = sys.argv[3] if len(sys.argv) > 3 else "fps_chain"
     rows = list(sqlite3.connect(db).execute("select name, start, end from kernels order by start"))
     marks = [i for i, r in enumerate(rows) if marker in r[0]]
     if len(marks) < steps + 1:
