@@ -518,18 +518,25 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
 //
 // FPS is m-1 dependent rounds, and a round of the pruned kernel is two barriers plus one wave scanning alone
 // (0.91 us).  Most of that dependence is not real: the next sample is the best candidate that the new sample does
-// not reach, and samples are far apart by construction.  Every wave keeps a record {best value, tie-break T, the
-// best point's coordinates, second-best value} of its 1024 points.  After ONE barrier wave 0 walks the 16 records:
-//   * the best VALID record is the next sample if its value is above every bound of the invalid waves;
-//   * taking a sample invalidates its own wave (whose new maximum is bounded by its second-best value) and every
-//     wave whose best point the sample reaches (d < value, the same f32 expression the scan evaluates, so the test
+// not reach, and samples are far apart by construction.  Every row of 16 lanes (256 curve-consecutive points) keeps a
+// record {best value, tie-break T, the best point's coordinates, second-best value}: 64 records per scene.  After
+// ONE barrier wave 0 walks the records (one per lane):
+//   * the best VALID record is the next sample if its value is above every bound of the invalidated rows;
+//   * taking a sample invalidates its own row (whose new maximum is bounded by its second-best value) and every
+//     row whose best point the sample reaches (d < value, the same f32 expression the scan evaluates, so the test
 //     is exact; bound max(second, d));  all other records stay exact -- their points may change, their best cannot.
 // The walk stops at the first candidate it cannot prove (or FPS_CHAIN_MAX); its samples go to LDS, and after the
 // second barrier every wave applies the whole chain to the clusters each sample can reach (the conservative box
-// test of the pruned kernel) and refreshes its record once.  Indices and the final `temp` are bit-identical to the
-// reference: skipped updates are no-ops, accepted samples are proven arg-maxima under the same total order.
-// Host replay on the bench scene (build/fps_chain_sim.py): 3.55 samples per synchronisation.
-constexpr int FPS_CHAIN_MAX = 8;
+// test of the pruned kernel) and refreshes its four records once (row all-reduces by DPP row rotations; every lane
+// selects its own best point, so there is no run-time register index and no scalar branch tree).  Indices and the
+// final `temp` are bit-identical to the reference: skipped updates are no-ops, accepted samples are proven arg-maxima
+// under the same total order.
+// Measured (MI355X, 16384 -> 4096, B = 2, profiles/r02_fps_variants.txt): 6.65 samples per synchronisation (616
+// instead of 4095; the host replay build/fps_chain_sim2.py predicts exactly that), 3.82 -> 2.46 ms.  Per
+// synchronisation ~10k cycles: busiest wave's updates + refresh ~4.0k, the walk ~3.7k (a dependent chain of
+// ~490 cycles per accepted sample on one wave), two barriers and their skew ~2.5k.
+constexpr int FPS_CHAIN_MAX = 16;
+constexpr int FPS_RECORDS = FPS_WAVES * 4;   // one record per row of 16 lanes (256 points)
 
 template <int P>
 __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __restrict__ xyz_all, float* __restrict__ temp_all,
@@ -537,8 +544,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
     constexpr int NS = FPS_THREADS * P;
     __shared__ uint32_t skey[NS];
     __shared__ float red[FPS_WAVES * 6];
-    __shared__ float4 rec_a[FPS_WAVES];     // {value, T, x, y} of the wave's best point
-    __shared__ float4 rec_b[FPS_WAVES];     // {z, second-best value, -, -}
+    __shared__ float4 rec_a[FPS_RECORDS];   // {value, T, x, y} of the best point of a row of 16 lanes (256 points)
+    __shared__ float2 rec_b[FPS_RECORDS];   // {z, second-best value of the row}
     __shared__ float4 chain[FPS_CHAIN_MAX]; // {x, y, z, T} of the samples decided at the last synchronisation
     __shared__ int chain_n;
     const int t = threadIdx.x;
@@ -608,29 +615,23 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
                 }
             lbest = bv[0]; bi = bx[0];
             const float lsec = sv[0];
-            const float wmax = wave_max_f32(lbest);
-            const unsigned long long eq = __ballot(lbest == wmax);
-            int lstar;
-            if (__builtin_popcountll(eq) == 1) {
-                lstar = (int)__builtin_ctzll(eq);
-            } else {
-                uint32_t myT = 0xffffffffu;
+            // my best point (every lane selects its own: no run-time register index, no scalar branch tree)
+            float mx = px[0], my = py[0], mz = pz[0];
+            uint32_t mT = kT[0];
 #pragma unroll
-                for (int i = 0; i < P; ++i) myT = (bi == i) ? kT[i] : myT;
-                const uint32_t tmin = wave_min_u32(lbest == wmax ? myT : 0xffffffffu);
-                const unsigned long long eq2 = __ballot(lbest == wmax && myT == tmin);
-                lstar = (int)__builtin_ctzll(eq2 | (1ull << 63));
+            for (int i = 1; i < P; ++i) {
+                const bool sel = bi == i;
+                mx = sel ? px[i] : mx; my = sel ? py[i] : my; mz = sel ? pz[i] : mz; mT = sel ? kT[i] : mT;
             }
-            lstar = __builtin_amdgcn_readfirstlane(lstar);
-            const int js = __builtin_amdgcn_readlane(bi, lstar);
-            float cx, cy, cz;
-            uint32_t wT;
-            fps_extract<0, P>(js, lstar, px, py, pz, kT, cx, cy, cz, wT);
-            // second-best value of the wave (as a multiset: a tie at the maximum makes it the maximum)
-            const float wsec = wave_max_f32(lane == lstar ? lsec : lbest);
-            if (lane == 0) {
-                rec_a[w] = make_float4(wmax, __builtin_bit_cast(float, wT), cx, cy);
-                rec_b[w] = make_float4(cz, wsec, 0.f, 0.f);
+            // one record per row of 16 lanes: the row's best (value, then tie-break), its second-best value (as a
+            // multiset: a tie at the maximum makes it the maximum)
+            const float rmax = row_allmax_f32(lbest);
+            const uint32_t rT = row_allmin_u32(lbest == rmax ? mT : 0xffffffffu);
+            const bool iswin = lbest == rmax && mT == rT;
+            const float rsec = row_allmax_f32(iswin ? lsec : lbest);
+            if (iswin) {       // an empty row (all lanes -1 / 0xffffffff) writes the same inert record from every lane
+                rec_a[t >> 4] = make_float4(lbest, __builtin_bit_cast(float, mT), mx, my);
+                rec_b[t >> 4] = make_float2(mz, rsec);
             }
             dirty = false;
 #ifdef PDA_FPS_STATS
@@ -644,21 +645,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
         FPS_T1(t_bar);
         FPS_T0();
         if (w == 0) {
-            // ---- the walk over the 16 records (lanes 0..15); an invalid record carries value -1 ----
-            float val = -1.f, rx = 0.f, ry = 0.f, rz = 0.f, sec = -1.f;
-            uint32_t rT = 0xffffffffu;
-            if (lane < FPS_WAVES) {
-                const float4 a = rec_a[lane], b = rec_b[lane];
-                val = a.x; rT = __builtin_bit_cast(uint32_t, a.y); rx = a.z; ry = a.w; rz = b.x; sec = b.y;
-            }
+            // ---- the walk over the 64 records (one per lane); an invalid record carries value -1 ----
+            const float4 ra = rec_a[lane];
+            const float2 rb = rec_b[lane];
+            float val = ra.x;
+            const uint32_t rT = __builtin_bit_cast(uint32_t, ra.y);
+            const float rx = ra.z, ry = ra.w, rz = rb.x, sec = rb.y;
             float maxbound = -1.f;
             float ox = 0.f, oy = 0.f, oz = 0.f;     // lane c collects sample c: one LDS write and one index store at the end
             uint32_t oT = 0u;
             const int rem = min(FPS_CHAIN_MAX, m - j);
             int c = 0;
             while (c < rem) {
-                const float cv = row0_max_f32(val);
-                if (cv < 0.f || maxbound >= cv) break;      // nothing valid left / an invalidated wave may hold more
+                const float cv = wave_max_f32(val);
+                if (cv < 0.f || maxbound >= cv) break;      // nothing valid left / an invalidated row may hold more
                 const unsigned long long eq = __ballot(val == cv);
                 uint32_t cT;
                 int wl;
@@ -666,8 +666,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
                     wl = (int)__builtin_ctzll(eq);
                     cT = (uint32_t)__builtin_amdgcn_readlane((int)rT, wl);
                 } else {
-                    cT = row0_min_u32(val == cv ? rT : 0xffffffffu);
-                    wl = (int)__builtin_ctzll(__ballot(val == cv && rT == cT) | (1ull << 63)) & (FPS_WAVES - 1);
+                    cT = wave_min_u32(val == cv ? rT : 0xffffffffu);
+                    wl = (int)__builtin_ctzll(__ballot(val == cv && rT == cT) | (1ull << 63));
                 }
                 const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), wl));
                 const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), wl));
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
                 const bool own = lane == wl;
                 const bool reach = d < val && !own;
                 maxbound = fmaxf(maxbound, ssec);
-                if (__ballot(reach) != 0ull) maxbound = fmaxf(maxbound, row0_max_f32(reach ? fmaxf(sec, d) : -1.f));
+                if (__ballot(reach) != 0ull) maxbound = fmaxf(maxbound, wave_max_f32(reach ? fmaxf(sec, d) : -1.f));
                 val = (reach || own) ? -1.f : val;
                 ++c;
             }

@@ -142,6 +142,21 @@ __device__ __forceinline__ void lds_barrier() {
     "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"     \
     "s_nop 1"
 
+// All-reduce inside each row of 16 lanes (row rotations): every lane gets its row's result.
+#define PDA_DPP_ROW_ALLREDUCE(OP)                                              \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"     \
+    "s_nop 1"
+__device__ __forceinline__ float row_allmax_f32(float v) {
+    asm volatile(PDA_DPP_ROW_ALLREDUCE("v_max_f32_dpp") : "+v"(v));
+    return v;
+}
+__device__ __forceinline__ uint32_t row_allmin_u32(uint32_t v) {
+    asm volatile(PDA_DPP_ROW_ALLREDUCE("v_min_u32_dpp") : "+v"(v));
+    return v;
+}
 __device__ __forceinline__ float wave_max_f32(float v) {
     asm volatile(PDA_DPP_REDUCE64("v_max_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
