@@ -178,15 +178,31 @@ class KernelTimers:
         t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.sa_mfma_events) * 1e-3
         fl = sum(f for _, _, f in self.sa_mfma_events)
         steps = max(1, len(self.fps_events))
-        util = pmc_record("mfma_util", "pda::lin_cols_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
-        return {"kernel": "lin_cols_kernel (SA group MLP, training form: %d launches per step, forward + input gradient)" % (
-                    len(self.sa_mfma_events) // steps),
-                "bound": "mfma", "achieved": fl / t / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": fl / t / 1e12 / F32_MFMA_PEAK_TF, "traffic": None, "ms_per_step": t / steps * 1e3,
+        from pdanet_amd import pointnet2_utils as pu
+        split = bool(getattr(pu, "SPLIT_GEMM", False))
+        if split:
+            util = pmc_record("mfma_util", "pda::lin_split_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns")
+            kern, note = "lin_split_kernel + lin_cols_kernel<gather>", (
+                "f32 contractions on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 terms (x = h + m + l "
+                "exactly; 6 of 9 products kept, error below the f32 fmaf chain's: tests/test_gemm_split.py); peak = the f32 "
+                "MFMA peak the same contraction had before (a fraction above 1 means faster than any f32-input MFMA kernel "
+                "can be); the bf16 pipe's ceiling for this form is 2500/6 = 416.7 TFLOP/s f32-equivalent "
+                "(frac_of_split_ceiling); the gather-fused first layers stay on lin_cols_kernel (f32 MFMA); launches "
+                "include the weight-packing kernel; PDA_SPLIT_GEMM=0 restores lin_cols_kernel everywhere")
+        else:
+            util = pmc_record("mfma_util", "pda::lin_cols_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
+            kern, note = "lin_cols_kernel", (
+                "v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction; "
+                "SURVEY 8(d): the layer-5 chain is 86.1 GFLOP per scene forward, the input gradients of layers 2-3 "
+                "add 77.5 (layer 1's 259-column input gradient stays on the library)")
+        ach = fl / t / 1e12
+        return {"kernel": "%s (SA group MLP, training form: %d launches per step, forward + input gradient)" % (
+                    kern, len(self.sa_mfma_events) // steps),
+                "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                "frac": ach / F32_MFMA_PEAK_TF, "frac_of_split_ceiling": (ach / (2500.0 / 6.0)) if split else None,
+                "traffic": None, "ms_per_step": t / steps * 1e3,
                 "gflop_per_step": fl / steps / 1e9, "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
-                "note": "v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction; "
-                        "SURVEY 8(d): the layer-5 chain is 86.1 GFLOP per scene forward, the input gradients of layers 2-3 "
-                        "add 77.5 (layer 1's 259-column input gradient stays on the library)"}
+                "note": note}
 
     def roofline_wgrad(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
