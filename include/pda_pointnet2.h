@@ -230,6 +230,10 @@ int64_t pda_linear_split_packed_bytes(int n_out, int k);
 int pda_linear_split_pack(const float *w, void *wf, int n_out, int k, int transposed_source, pda_stream_t stream);
 int pda_linear_split(const float *x, const void *wf, const float *bias, float *y, int64_t tokens, int k, int n_out,
                      int relu, pda_stream_t stream);
+/* The same arithmetic as an LDS-tiled GEMM (gemm_split_kernel): any k that is a multiple of 32, any n_out (the planes of
+ * pda_linear_split_pack are padded to 128 outputs), y [+]= x W^T [+ bias] [relu]; accumulate = 1 adds to y. */
+int pda_gemm_split(const float *x, const void *wf, const float *bias, float *y, int64_t tokens, int k, int n_out,
+                   int relu, int accumulate, pda_stream_t stream);
 /* Number of floats pda_sa_mlp_pack_weights writes for a (rows x cols) layer. */
 int pda_sa_mlp_packed_size(int rows, int cols, int first_layer);
 /* Re-orders a row-major (rows x cols) fp32 weight matrix into MFMA A-fragment order. */

@@ -56,6 +56,7 @@ SIGNATURES = {
     "pda_linear_split_packed_bytes": [_i, _i],
     "pda_linear_split_pack": [_vp, _vp, _i, _i, _i, _vp],
     "pda_linear_split": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
+    "pda_gemm_split": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _i, _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],
     "pda_sa_mlp_pack_weights": [_vp, _vp, _i, _i, _i, _vp],
     # include/pda_train.h

@@ -224,6 +224,136 @@ void lin_split_kernel(const LinSplitParams p) {
     GS_MARK(10);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// gemm_split_kernel: the same arithmetic as an LDS-tiled GEMM for ANY K (multiple of 16) and any N:
+//   Y (T, N) [+]= X (T, K) W^T [+ bias] [relu].
+// lin_split_kernel keeps a wave's rows in registers, which caps K at 512 and leaves one wave per SIMD (nothing overlaps
+// its row loads and output stores).  Here a workgroup (4 waves, 2 x 2) owns a 128-token x 128-output tile and both
+// operands stream through a 3-slot LDS ring in K = 16 steps by LDS-DMA: X as f32 rows of 64 bytes whose 16-byte chunks
+// are XOR-swizzled through the SOURCE address (chunk c of row r sits in chunk slot c ^ ((r >> 2) & 3): the two
+// ds_read_b128 of a fragment are conflict-free), W as the packed bf16 planes of split_pack_kernel.  A wave computes
+// 64 x 64 (2 x 2 MFMA tiles): per K step it splits its two X fragments into bf16 terms (88 VALU) for 24 MFMAs.  60 KB of
+// LDS and ~150 registers: two workgroups per CU, so one's stores and barrier waits sit under the other's MFMAs.
+struct GemmSplitParams {
+    const float* x;         // (T, K) row-major
+    const uint4* wf;        // packed planes (split_pack_kernel)
+    const float* bias;      // (N) or null
+    float* y;               // (T, N) row-major
+    int64_t tokens;
+    int k, n_out, chunks, ksteps, relu, accum;
+};
+
+constexpr int GT_XCHUNKS = 128 * 4;                  // uint4 per X tile (128 rows x 64 bytes)
+constexpr int GT_SLOT = GT_XCHUNKS + GS_KSTEP;       // + 768 uint4 of W planes = 20 KB per slot
+
+__global__ __launch_bounds__(256, 2)
+void gemm_split_kernel(const GemmSplitParams p) {
+    __shared__ uint4 ring[3 * GT_SLOT];
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int wt = w & 1, wo = w >> 1;
+    const int nc = (int)(blockIdx.x % (unsigned)p.chunks);          // output chunk fastest: the workgroups that share an
+    const int64_t tok0 = (int64_t)(blockIdx.x / (unsigned)p.chunks) * 128;   // X tile run together (L2)
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
+    // DMA roles.  X: instruction i = 2w + e covers LDS chunks 64 i .. 64 i + 63 (16 rows); W: instructions 3w .. 3w + 2.
+    const float* xsrc[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int pch = 64 * (2 * w + e) + lane, row = pch >> 2, cl = pch & 3, c = cl ^ ((row >> 2) & 3);
+        const int64_t tok = tok0 + row < p.tokens ? tok0 + row : p.tokens - 1;
+        xsrc[e] = p.x + tok * p.k + 4 * c;
+    }
+    const uint4* wsrc = p.wf + (size_t)nc * p.ksteps * GS_KSTEP + 64 * 3 * w + lane;
+    auto issue = [&](int s, int slot) {
+        const int ss = s < p.ksteps ? s : p.ksteps - 1;      // behind the last step: the last tile again, never read
+        const uint32_t base = ring_base + slot * (GT_SLOT * 16);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) glds16(reinterpret_cast<const uint4*>(xsrc[e] + 16 * ss), base + (2 * w + e) * 1024);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) glds16(wsrc + (size_t)ss * GS_KSTEP + 64 * e, base + GT_XCHUNKS * 16 + (3 * w + e) * 1024);
+    };
+    gs_f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    // fragment addresses inside a slot (uint4 units)
+    int xoff[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int row = wt * 64 + tt * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) xoff[tt][e] = row * 4 + ((2 * h + e) ^ ((row >> 2) & 3));
+    }
+    const int woff = GT_XCHUNKS + (wo * 2 * 3) * 64 + lane;
+    issue(0, 0);
+    issue(1, 1);
+    int slot = 0;
+    for (int s = 0; s < p.ksteps; ++s, slot = slot == 2 ? 0 : slot + 1) {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // my part of tile s has landed (tile s + 1 may be in flight)
+        __builtin_amdgcn_s_barrier();                          // everyone's has; everyone is done with tile s - 1
+        asm volatile("" ::: "memory");
+        issue(s + 2, slot == 0 ? 2 : slot - 1);
+        const uint4* buf = ring + slot * GT_SLOT;
+        uint4 wfr[2][3];
+#pragma unroll
+        for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfr[ot][pl] = buf[woff + (ot * 3 + pl) * 64];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const uint4 a = buf[xoff[tt][0]], b = buf[xoff[tt][1]];
+            uint32_t bh[4], bm[4], bl[4];
+            split2(__uint_as_float(a.x), __uint_as_float(a.y), bh[0], bm[0], bl[0]);
+            split2(__uint_as_float(a.z), __uint_as_float(a.w), bh[1], bm[1], bl[1]);
+            split2(__uint_as_float(b.x), __uint_as_float(b.y), bh[2], bm[2], bl[2]);
+            split2(__uint_as_float(b.z), __uint_as_float(b.w), bh[3], bm[3], bl[3]);
+            const gs_bf16x8 Xh = __builtin_bit_cast(gs_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const gs_bf16x8 Xm = __builtin_bit_cast(gs_bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+            const gs_bf16x8 Xl = __builtin_bit_cast(gs_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                const gs_bf16x8 Wh = __builtin_bit_cast(gs_bf16x8, wfr[ot][0]);
+                const gs_bf16x8 Wm = __builtin_bit_cast(gs_bf16x8, wfr[ot][1]);
+                const gs_bf16x8 Wl = __builtin_bit_cast(gs_bf16x8, wfr[ot][2]);
+                gs_f32x16 c = acc[tt][ot];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xl, Wh, c, 0, 0, 0);    // smallest terms first
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wh, c, 0, 0, 0);
+                acc[tt][ot] = c;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the two dummy tiles: no DMA may outlive the wave's LDS
+    // rows of a 32 x 32 tile: token (i & 3) + 8 (i >> 2) + 4 h; column: output nc * 128 + (2 wo + ot) * 32 + r
+#pragma unroll
+    for (int ot = 0; ot < 2; ++ot) {
+        const int col = nc * 128 + (wo * 2 + ot) * 32 + r;
+        if (col >= p.n_out) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int64_t trow = tok0 + wt * 64 + tt * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t tok = trow + (i & 3) + 8 * (i >> 2);
+                if (tok < p.tokens) {
+                    float* dst = p.y + tok * p.n_out + col;
+                    float v = acc[tt][ot][i] + bias;
+                    if (p.accum) v += *dst;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace pda
 
 PDA_API int64_t pda_linear_split_packed_bytes(int n_out, int k) {
@@ -268,4 +398,30 @@ PDA_API int pda_linear_split(const float* x, const void* wf, const float* bias, 
             return PDA_ERR_UNSUPPORTED;
     }
     return pda::check_launch("pda_linear_split");
+}
+
+PDA_API int pda_gemm_split(const float* x, const void* wf, const float* bias, float* y, int64_t tokens, int k, int n_out,
+                           int relu, int accumulate, pda_stream_t stream) {
+    PDA_REQUIRE(tokens >= 0 && k > 0 && n_out > 0, "pda_gemm_split: bad size");
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(x && wf && y && (((uintptr_t)x | (uintptr_t)wf) & 15) == 0, "pda_gemm_split: null or misaligned pointer");
+    if (k % 16 != 0) {
+        pda::set_error("pda_gemm_split: K=%d must be a multiple of 16", k);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::GemmSplitParams p{};
+    p.x = x; p.wf = (const uint4*)wf; p.bias = bias; p.y = y; p.tokens = tokens; p.k = k; p.n_out = n_out;
+    p.chunks = pda::divup(n_out, 128); p.ksteps = pda::divup(k, 32) * 2; p.relu = relu; p.accum = accumulate;
+    // the packed planes hold ceil(K / 32) * 2 K steps (zero beyond K); X is only read up to K: walk K / 16 steps
+    const int64_t blocks = pda::divup64(tokens, 128) * p.chunks;
+    PDA_REQUIRE(blocks < (1ll << 31), "pda_gemm_split: too many tiles");
+    const int packed_steps = p.ksteps;
+    p.ksteps = k / 16;
+    // the W tiles of a chunk are packed_steps apart
+    if (packed_steps != p.ksteps) {
+        pda::set_error("pda_gemm_split: K=%d must be a multiple of 32 (packed planes come in pairs of K steps)", k);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    hipLaunchKernelGGL(pda::gemm_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
+    return pda::check_launch("pda_gemm_split");
 }

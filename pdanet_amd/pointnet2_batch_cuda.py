@@ -596,6 +596,17 @@ def linear_split(x, wf, bias, y, tokens, k, n_out, relu=False):
     return 1
 
 
+def gemm_split(x, wf, bias, y, tokens, k, n_out, relu=False, accumulate=False):
+    """y (tokens, n_out) [+]= x (tokens, k) W^T [+ bias] [relu] on gemm_split_kernel (any k % 32 == 0, any n_out)."""
+    _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
+    _numel_ok(wf, int(_lib.load().pda_linear_split_packed_bytes(int(n_out), int(k))), "wf")
+    if bias is not None:
+        _numel_ok(bias, n_out, "bias")
+    _call("pda_gemm_split", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), None if bias is None else _chk(bias, "bias", F32),
+          _chk(y, "y", F32), tokens, k, n_out, 1 if relu else 0, 1 if accumulate else 0)
+    return 1
+
+
 def sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, b, n, m, c, nsample, n_out):
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(feats_pm, b * n * c, "feats_pm")
     _numel_ok(idx, b * m * nsample, "idx"); _numel_ok(y, b * m * nsample * n_out, "y")

@@ -477,7 +477,7 @@ class LinearLongTokens(Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        return torch.nn.functional.linear(x, weight, bias)
+        return _gemm_nt(x.reshape(-1, x.shape[-1]), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
     def backward(ctx, grad_out):
@@ -485,7 +485,7 @@ class LinearLongTokens(Function):
         grad_out = grad_out.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = grad_out.matmul(weight)
+            gx = _gemm_nn(grad_out.reshape(-1, grad_out.shape[-1]), weight).view(*grad_out.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             n_out, n_in = weight.shape
             xc = x.contiguous()
@@ -537,6 +537,51 @@ def _b16p(p):
     pb = p.detach().to(torch.bfloat16)
     _B16_PARAMS[key] = (stamp, weakref.ref(p, lambda _r, k=key: _B16_PARAMS.pop(k, None)), pb)
     return pb
+
+
+# SPLIT_GEMM: f32 contractions run on the bf16 matrix cores with three-term bf16 operands (csrc/gemm_split.hip: f32-grade
+# results; LinearColsMFMA: lin_split_kernel, 1.3-1.5x the f32 MFMA kernel; the encoder projections and input gradients:
+# gemm_split_kernel, 1.1-1.35x the library's f32 GEMMs).  False (PDA_SPLIT_GEMM=0): lin_cols_kernel / the library.
+SPLIT_GEMM = os.environ.get("PDA_SPLIT_GEMM", "1") != "0"
+
+# ---- f32 GEMMs of the step on csrc/gemm_split.hip (bf16 matrix cores, three-term operands, f32-grade error) ----------
+SPLIT_GEMM_MIN_TOKENS = 4096      # below: the library (one small launch) is as fast and saves the packing launch
+
+
+def _split_gemm_ok(x2d, k):
+    return (SPLIT_GEMM and x2d.is_cuda and x2d.dtype == torch.float32 and k % 32 == 0 and x2d.shape[0] >= SPLIT_GEMM_MIN_TOKENS
+            and not DENSE_BF16 and not torch.is_autocast_enabled())
+
+
+def _gemm_nt(x2d, w, bias=None, relu=False):
+    """relu?(x2d (T, K) @ w (N, K)^T + bias) in f32."""
+    n_out, k = w.shape
+    if _split_gemm_ok(x2d, k) and w.dtype == torch.float32:
+        x2d = x2d.contiguous()
+        T = x2d.shape[0]
+        y = torch.empty((T, n_out), dtype=torch.float32, device=x2d.device)
+        wf = pointnet2.linear_split_pack(w.detach().contiguous(), n_out, k)
+        pointnet2.gemm_split(x2d, wf, None if bias is None else bias.detach().contiguous(), y, T, k, n_out, relu=relu)
+        return y
+    if relu and bias is not None:
+        return torch._addmm_activation(bias, x2d, w.t())
+    y = torch.nn.functional.linear(x2d, w, bias)
+    return torch.relu_(y) if relu else y
+
+
+def _gemm_nn(g2d, w, acc=None):
+    """g2d (T, N) @ w (N, K) [+ acc, in place: acc is owned by the caller] in f32: the input gradient of y = x w^T."""
+    n, k_out = w.shape
+    if _split_gemm_ok(g2d, n) and w.dtype == torch.float32:
+        g2d = g2d.contiguous()
+        T = g2d.shape[0]
+        y = acc if acc is not None else torch.empty((T, k_out), dtype=torch.float32, device=g2d.device)
+        wf = pointnet2.linear_split_pack(w.detach().contiguous(), k_out, n, transposed_source=True)
+        pointnet2.gemm_split(g2d, wf, None, y, T, n, k_out, accumulate=acc is not None)
+        return y
+    if acc is not None:
+        return acc.addmm_(g2d, w)
+    return g2d.mm(w)
 
 
 def _mm_nt(x2d, w, bf16):
@@ -702,14 +747,14 @@ class TransformerBlock(Function):
             ffn = torch.addmm(_b16p(b2), h, _b16p(w2).t()).view(G, S, D)
         else:
             pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, T, D, eps1)
-            qkv = torch.nn.functional.linear(src1, in_w, in_b)
+            qkv = _gemm_nt(src1.view(T, D), in_w, in_b).view(G, S, 3 * D)
             a = torch.empty((G, S, D), **f32)
             pointnet2.group_attention_fwd(qkv, a, lse, G, S, heads, hd)
-            proj = torch.nn.functional.linear(a, out_w, out_b)
+            proj = _gemm_nt(a.view(T, D), out_w, out_b).view(G, S, D)
             pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, T, D, eps2)
             del proj
-            h = torch._addmm_activation(b1, src2.view(T, D), w1.t()).view(G, S, -1)     # relu(src2 W1^T + b1), epilogue ReLU
-            ffn = torch.nn.functional.linear(h, w2, b2)
+            h = _gemm_nt(src2.view(T, D), w1, b1, relu=True).view(G, S, -1)     # relu(src2 W1^T + b1), epilogue ReLU
+            ffn = _gemm_nt(h.view(T, -1), w2, b2).view(G, S, D)
             src1_s, a_s, src2_s, h_s = src1.view(T, D), a.view(T, D), src2.view(T, D), h.view(T, -1)
         if pool:   # max over the tokens of a group of src2 + ffn, without materialising the sum
             y = torch.empty((G, D), **f32)
@@ -742,7 +787,7 @@ class TransformerBlock(Function):
             dy2 = dy.contiguous().view(T, D)
             dy_g = _b16(dy2) if bf16 else dy2
         # y = src2 + h W2^T + b2
-        d_h = torch.mm(dy_g, _b16p(w2)) if bf16 else dy_g.mm(w2)
+        d_h = torch.mm(dy_g, _b16p(w2)) if bf16 else _gemm_nn(dy_g, w2)
         if bf16 and ctx.pool:   # the scattered gradient's column sums are those of the (G, D) tensor it was scattered from
             gw2, gb2 = _wgrad(h_s, dy_g, w2, False, True)[0], dy.sum(0)
         else:
@@ -752,7 +797,7 @@ class TransformerBlock(Function):
         # h = relu(src2 W1^T + b1); the gradient of src2 is dy (residual branch) + d_h W1: the LayerNorm backward
         # kernel adds its two incoming gradients on the fly (torch.addmm would first copy dy into its output)
         gw1, gb1 = _wgrad(src2_s, d_h, w1, True, bf16)
-        d_lin1 = torch.mm(d_h, _b16p(w1)) if bf16 else d_h.mm(w1)
+        d_lin1 = torch.mm(d_h, _b16p(w1)) if bf16 else _gemm_nn(d_h, w1)
         del d_h
         # src2 = LayerNorm2(ssum), ssum = src1 + a Wo^T + bo
         d_s = torch.empty((T, D), **f32)
@@ -761,7 +806,7 @@ class TransformerBlock(Function):
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, T, D, grad_y2=d_lin1, grad_x_bf16=ds_g if bf16 else None)
         del d_lin1
-        d_a = torch.mm(ds_g, _b16p(out_w)) if bf16 else d_s.mm(out_w)
+        d_a = torch.mm(ds_g, _b16p(out_w)) if bf16 else _gemm_nn(d_s, out_w)
         gwo, gbo = _wgrad(a_s, ds_g, out_w, True, bf16)
         del ds_g
         dqkv = torch.empty_like(qkv)
@@ -769,7 +814,7 @@ class TransformerBlock(Function):
         del d_a
         dqkv2 = dqkv.view(T, 3 * D)
         gwi, gbi = _wgrad(src1_s, dqkv2, in_w, True, bf16)
-        d_src1 = _mm_nn(dqkv2, in_w, bf16, acc=d_s)     # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
+        d_src1 = _mm_nn(dqkv2, in_w, True, acc=d_s) if bf16 else _gemm_nn(dqkv2, in_w, acc=d_s)   # d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv, dqkv2
         d_x = torch.empty_like(x)
         gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)
@@ -805,9 +850,6 @@ def _sa_timed(flops, fn):
     ev.append((e0, e1, flops))
 
 
-# SPLIT_GEMM: the contractions of LinearColsMFMA run on the bf16 matrix cores with three-term bf16 operands
-# (csrc/gemm_split.hip: f32-grade results, measured 1.3-1.5x the f32 MFMA kernel); False: lin_cols_kernel (f32 MFMA).
-SPLIT_GEMM = os.environ.get("PDA_SPLIT_GEMM", "1") != "0"
 
 
 def _lin_cols(x2, weight, y, T, k, n_out, transposed):
@@ -854,7 +896,7 @@ class LinearColsMFMA(Function):
                 # dX = dY W: the same kernel with the weights packed from the transposed source
                 _lin_cols(g2, weight.contiguous(), gx, T, n_out, k, True)
             else:
-                gx = g2.mm(weight)
+                gx = _gemm_nn(g2, weight)
             gx = gx.view(ctx.x_shape)
         if ctx.needs_input_grad[1]:
             gw = _wgrad(x2, g2, weight, False)[0]
@@ -899,7 +941,7 @@ class SaGatherLinear(Function):
                 gw = _wgrad(x0, g2, weight, False)[0]
                 del x0
             if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                gx0 = g2.mm(weight).view(B, M, ns, -1)
+                gx0 = _gemm_nn(g2, weight).view(B, M, ns, -1)
                 if ctx.needs_input_grad[1]:
                     g_new = -gx0[..., :3].sum(dim=2)
                 if ctx.needs_input_grad[2]:
@@ -1084,14 +1126,14 @@ class RaggedTransformerBlock(Function):
         st1, st2 = torch.empty((U, 2), **f32), torch.empty((U, 2), **f32)
         lse = torch.empty((G, heads, S), **f32)
         pointnet2.layer_norm_fwd(x, None, n1w, n1b, None, src1, st1, U, D, eps1)
-        qkv = torch.nn.functional.linear(src1, in_w, in_b)
+        qkv = _gemm_nt(src1, in_w, in_b)
         a = torch.empty((U, D), **f32)
         pointnet2.group_attention_ragged_fwd(qkv, plan.cnt, plan.off, a, lse, U, G, S, heads, hd)
-        proj = torch.nn.functional.linear(a, out_w, out_b)
+        proj = _gemm_nt(a, out_w, out_b)
         pointnet2.layer_norm_fwd(proj, src1, n2w, n2b, ssum, src2, st2, U, D, eps2)
         del proj
-        h = torch._addmm_activation(b1, src2, w1.t())          # relu(src2 W1^T + b1), ReLU in the GEMM epilogue
-        ffn = torch.nn.functional.linear(h, w2, b2)
+        h = _gemm_nt(src2, w1, b1, relu=True)                   # relu(src2 W1^T + b1), ReLU in the GEMM epilogue
+        ffn = _gemm_nt(h, w2, b2)
         y = torch.empty((G, D), **f32)
         arg = torch.empty((G, D), dtype=torch.uint8, device=dev)
         pointnet2.add_max_pool_ragged(src2, ffn, plan.cnt, plan.off, y, arg, U, G, D)
@@ -1111,24 +1153,24 @@ class RaggedTransformerBlock(Function):
         f32 = dict(dtype=torch.float32, device=dev)
         dy2 = torch.empty((U, D), **f32)
         pointnet2.max_pool_scatter_ragged(dy.contiguous(), arg, rowmap, off, dy2, U, G, S, D)
-        d_h = dy2.mm(w2)
+        d_h = _gemm_nn(dy2, w2)
         gw2, gb2 = _wgrad_ragged(h, dy2, w2, True)
         d_h = torch.ops.aten.threshold_backward(d_h, h, 0)
         gw1, gb1 = _wgrad_ragged(src2, d_h, w1, True)
-        d_lin1 = d_h.mm(w1)
+        d_lin1 = _gemm_nn(d_h, w1)
         del d_h
         d_s = torch.empty((U, D), **f32)
         gn2w, gn2b = torch.empty_like(n2w), torch.empty_like(n2w)
         scratch = torch.empty((pointnet2.layer_norm_scratch_bytes(D),), dtype=torch.uint8, device=dev)
         pointnet2.layer_norm_bwd(ssum, dy2, n2w, st2, d_s, gn2w, gn2b, scratch, U, D, grad_y2=d_lin1)
         del d_lin1
-        d_a = d_s.mm(out_w)
+        d_a = _gemm_nn(d_s, out_w)
         gwo, gbo = _wgrad_ragged(a, d_s, out_w, True)
         dqkv = torch.empty_like(qkv)
         pointnet2.group_attention_ragged_bwd(qkv, d_a, lse, cnt, off, dqkv, U, G, S, heads, hd)
         del d_a
         gwi, gbi = _wgrad_ragged(src1, dqkv, in_w, True)
-        d_src1 = _mm_nn(dqkv, in_w, False, acc=d_s)        # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
+        d_src1 = _gemm_nn(dqkv, in_w, acc=d_s)             # residual gradient d_s + dqkv Win, accumulated (d_s is ours)
         del dqkv
         d_x = torch.empty_like(x)
         gn1w, gn1b = torch.empty_like(n1w), torch.empty_like(n1w)

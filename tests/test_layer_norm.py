@@ -50,25 +50,41 @@ def test_transformer_layer_fused_equals_unfused():
         assert torch.allclose(a, b, atol=1e-9 + 3e-5 * b.abs().max().item())
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("G,S,D,ff", [(300, 16, 256, 128), (2100, 32, 256, 128), (1100, 32, 512, 256)])
-def test_transformer_block_node_equals_op_by_op(G, S, D, ff):
-    """One-node transformer (hand-scheduled backward) == the same layer executed op by op through autograd."""
-    from pdanet_amd import pointnet2_modules as pm
+def test_transformer_block_node_equals_op_by_op(G, S, D, ff, split):
+    """One-node transformer (hand-scheduled backward) == the same layer executed op by op through autograd.
+    split = False: both on the library's f32 GEMMs (same kernels, the comparison is to rounding).  split = True: the node's
+    projections run on csrc/gemm_split.hip from 4096 tokens on; a pre-activation within rounding of zero then lands on the
+    other side of the ReLU kink in a few of ~10^7 units and moves the gradients of that unit's group (32 tokens x D entries)
+    by one unit's contribution -- both are valid subgradients -- so the bar is: outputs to rounding, every gradient tensor
+    within 1e-3 in Frobenius norm, no entry far off."""
+    from pdanet_amd import pointnet2_modules as pm, pointnet2_utils as pu
     torch.manual_seed(G)
     layer = pm.TransformerEncoderLayerPreNorm(d_model=D, nhead=4, dim_feedforward=ff, dropout=0.0).cuda()
     x = torch.randn(G, S, D, device="cuda", requires_grad=True)
     params = [p for p in layer.parameters()]
     res = []
-    for flag in (True, False):
-        pm.FUSED_TRANSFORMER_BLOCK = flag
-        y = pm._transformer_batch_first(layer, x)
-        g = torch.autograd.grad(y.square().mean() + y.max(dim=1)[0].sum() * 1e-3, [x] + params)
-        res.append((y.detach(), g))
-    pm.FUSED_TRANSFORMER_BLOCK = True
+    keep = pu.SPLIT_GEMM
+    try:
+        pu.SPLIT_GEMM = split
+        for flag in (True, False):
+            pm.FUSED_TRANSFORMER_BLOCK = flag
+            y = pm._transformer_batch_first(layer, x)
+            g = torch.autograd.grad(y.square().mean() + torch.logsumexp(y, dim=1).sum() * 1e-3, [x] + params)
+            res.append((y.detach(), g))
+    finally:
+        pm.FUSED_TRANSFORMER_BLOCK = True
+        pu.SPLIT_GEMM = keep
     assert torch.allclose(res[0][0], res[1][0], atol=3e-5, rtol=1e-5)
     for a, b in zip(res[0][1], res[1][1]):
         assert a.shape == b.shape
-        assert (a - b).abs().max().item() <= 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
+        tol = 3e-5 * max(b.abs().max().item(), 1e-6) + 1e-9
+        diff = (a - b).abs()
+        if split:     # a flipped unit moves one row of a weight gradient and one group's rows of dx: bound the whole tensor
+            assert diff.norm().item() <= 1e-3 * b.norm().item() + 1e-9 and diff.max().item() <= 300 * tol
+        else:
+            assert diff.max().item() <= tol
 
 
 @pytest.mark.parametrize("G,S,D", [(7, 16, 256), (1000, 32, 512), (33, 8, 64)])

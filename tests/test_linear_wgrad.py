@@ -20,9 +20,13 @@ def test_gradients(tokens, n_in, n_out, bias):
     y = pu.LinearLongTokens.apply(x, w, b)
     g = torch.autograd.grad(y, [x, w] + ([b] if bias else []), go)
     gw_ref = go.double().t() @ x.detach().double()
-    assert torch.allclose(y, F.linear(x, w, b))
+    # forward and input gradient: f32 GEMMs (the library, or csrc/gemm_split.hip from 4096 tokens): error at the level of
+    # an f32 fmaf chain, relative to sum |x||w| -- a second f32 GEMM of another summation order is not the yardstick
+    xd, wd = x.detach().double(), w.detach().double()
+    y_ref = xd @ wd.t() + (b.detach().double() if bias else 0)
+    assert ((y.double() - y_ref).abs() / (xd.abs() @ wd.abs().t() + 1e-30)).max().item() < 2e-6
     assert (g[1].double() - gw_ref).abs().max().item() < 3e-5 * gw_ref.abs().max().item()
-    assert torch.allclose(g[0], go @ w.detach(), atol=1e-5, rtol=1e-5)
+    assert ((g[0].double() - go.double() @ wd).abs() / (go.double().abs() @ wd.abs() + 1e-30)).max().item() < 2e-6
     if bias:
         gb_ref = go.double().sum(0)
         assert (g[2].double() - gb_ref).abs().max().item() < 3e-5 * gb_ref.abs().max().item() + 1e-4
