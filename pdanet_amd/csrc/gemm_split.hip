@@ -24,6 +24,8 @@
 //       global -> registers -> LDS, the loads of the next tile in flight under the MFMAs of the current one.
 #include "pda_common.h"
 
+#include <stdlib.h>
+
 namespace pda {
 
 typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
@@ -306,10 +308,15 @@ void gemm_split_kernel(const GemmSplitParams p) {
         for (int tt = 0; tt < 2; ++tt) {
             const uint4 a = buf[xoff[tt][0]], b = buf[xoff[tt][1]];
             uint32_t bh[4], bm[4], bl[4];
+#ifdef GS_NOSPLIT
+            bh[0] = a.x; bh[1] = a.y; bh[2] = a.z; bh[3] = a.w; bm[0] = b.x; bm[1] = b.y; bm[2] = b.z; bm[3] = b.w;
+            bl[0] = a.x ^ b.x; bl[1] = a.y ^ b.y; bl[2] = a.z ^ b.z; bl[3] = a.w ^ b.w;
+#else
             split2(__uint_as_float(a.x), __uint_as_float(a.y), bh[0], bm[0], bl[0]);
             split2(__uint_as_float(a.z), __uint_as_float(a.w), bh[1], bm[1], bl[1]);
             split2(__uint_as_float(b.x), __uint_as_float(b.y), bh[2], bm[2], bl[2]);
             split2(__uint_as_float(b.z), __uint_as_float(b.w), bh[3], bm[3], bl[3]);
+#endif
             const gs_bf16x8 Xh = __builtin_bit_cast(gs_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
             const gs_bf16x8 Xm = __builtin_bit_cast(gs_bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
             const gs_bf16x8 Xl = __builtin_bit_cast(gs_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
@@ -347,6 +354,137 @@ void gemm_split_kernel(const GemmSplitParams p) {
                     float v = acc[tt][ot][i] + bias;
                     if (p.accum) v += *dst;
                     if (p.relu) v = fmaxf(v, 0.f);
+#ifdef GS_NOSTORE
+                    if (v == 12345.678f)
+#endif
+                    *dst = v;
+                }
+            }
+        }
+    }
+}
+
+// gemm_split_wide_kernel: 8 waves (4 x 2) per workgroup = 256 tokens x 256 outputs, a wave computes 64 x 128 (2 x 4 MFMA
+// tiles, 128 accumulator registers).  Against the 128 x 128 form this halves what sits between the MFMAs: per K step a wave
+// splits two X fragments (88 VALU) and reads 16 fragments for 48 MFMAs instead of 24, and there is one barrier per 48.
+// (Measured on the 128 x 128 form: without the split AND without the stores it still stops at 200 TFLOP/s f32-equivalent --
+// the loop's own LDS reads, DMA issue and barrier are the limit there; a five-slot ring with the DMA four steps ahead changed
+// nothing, so DMA latency is not.)  One workgroup per CU (3 slots x 40 KB), two waves per SIMD.
+constexpr int GW_XCHUNKS = 256 * 4;                  // uint4 per X tile (256 rows x 64 bytes)
+constexpr int GW_SLOT = GW_XCHUNKS + 2 * GS_KSTEP;   // + two 128-output chunks of W planes = 40 KB
+constexpr int GW_SLOTS = 3;
+
+__global__ __launch_bounds__(512, 1)
+void gemm_split_wide_kernel(const GemmSplitParams p) {
+    extern __shared__ uint4 ring[];                  // GW_SLOTS * GW_SLOT
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = lane >> 5, r = lane & 31;
+    const int wt = w & 3, wo = w >> 2;
+    const int wide_chunks = (p.chunks + 1) >> 1;
+    const int ncb = (int)(blockIdx.x % (unsigned)wide_chunks);
+    const int64_t tok0 = (int64_t)(blockIdx.x / (unsigned)wide_chunks) * 256;
+    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
+    const float* xsrc[2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int pch = 64 * (2 * w + e) + lane, row = pch >> 2, cl = pch & 3, c = cl ^ ((row >> 2) & 3);
+        const int64_t tok = tok0 + row < p.tokens ? tok0 + row : p.tokens - 1;
+        xsrc[e] = p.x + tok * p.k + 4 * c;
+    }
+    // W pieces 3w .. 3w + 2 of the 24 (12 per 128-output chunk); an odd chunk count repeats the last chunk (its columns are
+    // beyond n_out and never stored)
+    const uint4* wsrc[3];
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+        const int piece = 3 * w + e, half = piece / 12, j = piece - 12 * half;
+        int chunk = 2 * ncb + half;
+        if (chunk >= p.chunks) chunk = p.chunks - 1;
+        wsrc[e] = p.wf + (size_t)chunk * p.ksteps * GS_KSTEP + 64 * j + lane;
+    }
+    auto issue = [&](int s, int slot) {
+        const int ss = s < p.ksteps ? s : p.ksteps - 1;
+        const uint32_t base = ring_base + slot * (GW_SLOT * 16);
+#pragma unroll
+        for (int e = 0; e < 2; ++e) glds16(reinterpret_cast<const uint4*>(xsrc[e] + 16 * ss), base + (2 * w + e) * 1024);
+#pragma unroll
+        for (int e = 0; e < 3; ++e) glds16(wsrc[e] + (size_t)ss * GS_KSTEP, base + GW_XCHUNKS * 16 + (3 * w + e) * 1024);
+    };
+    gs_f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    int xoff[2][2];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        const int row = wt * 64 + tt * 32 + r;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) xoff[tt][e] = row * 4 + ((2 * h + e) ^ ((row >> 2) & 3));
+    }
+    const int woff = GW_XCHUNKS + wo * GS_KSTEP + lane;       // my 128-output chunk: [row block][plane][lane]
+    issue(0, 0);
+    issue(1, 1);
+    int slot = 0;
+    for (int s = 0; s < p.ksteps; ++s, slot = slot == GW_SLOTS - 1 ? 0 : slot + 1) {
+        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // my part of tile s has landed (tile s + 1 may be in flight)
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue(s + 2, slot == 0 ? GW_SLOTS - 1 : slot - 1);
+        const uint4* buf = ring + slot * GW_SLOT;
+        uint4 wfr[4][3];
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wfr[ot][pl] = buf[woff + (ot * 3 + pl) * 64];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const uint4 a = buf[xoff[tt][0]], b = buf[xoff[tt][1]];
+            uint32_t bh[4], bm[4], bl[4];
+            split2(__uint_as_float(a.x), __uint_as_float(a.y), bh[0], bm[0], bl[0]);
+            split2(__uint_as_float(a.z), __uint_as_float(a.w), bh[1], bm[1], bl[1]);
+            split2(__uint_as_float(b.x), __uint_as_float(b.y), bh[2], bm[2], bl[2]);
+            split2(__uint_as_float(b.z), __uint_as_float(b.w), bh[3], bm[3], bl[3]);
+            const gs_bf16x8 Xh = __builtin_bit_cast(gs_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
+            const gs_bf16x8 Xm = __builtin_bit_cast(gs_bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
+            const gs_bf16x8 Xl = __builtin_bit_cast(gs_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) {
+                const gs_bf16x8 Wh = __builtin_bit_cast(gs_bf16x8, wfr[ot][0]);
+                const gs_bf16x8 Wm = __builtin_bit_cast(gs_bf16x8, wfr[ot][1]);
+                const gs_bf16x8 Wl = __builtin_bit_cast(gs_bf16x8, wfr[ot][2]);
+                gs_f32x16 c = acc[tt][ot];
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xl, Wh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wl, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wh, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wm, c, 0, 0, 0);
+                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wh, c, 0, 0, 0);
+                acc[tt][ot] = c;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int ot = 0; ot < 4; ++ot) {
+        const int col = (2 * ncb + wo) * 128 + ot * 32 + r;
+        if (col >= p.n_out) continue;
+        const float bias = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int64_t trow = tok0 + wt * 64 + tt * 32 + 4 * h;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t tok = trow + (i & 3) + 8 * (i >> 2);
+                if (tok < p.tokens) {
+                    float* dst = p.y + tok * p.n_out + col;
+                    float v = acc[tt][ot][i] + bias;
+                    if (p.accum) v += *dst;
+                    if (p.relu) v = fmaxf(v, 0.f);
+#ifdef GS_NOSTORE
+                    if (v == 12345.678f)
+#endif
                     *dst = v;
                 }
             }
@@ -421,6 +559,18 @@ PDA_API int pda_gemm_split(const float* x, const void* wf, const float* bias, fl
     if (packed_steps != p.ksteps) {
         pda::set_error("pda_gemm_split: K=%d must be a multiple of 32 (packed planes come in pairs of K steps)", k);
         return PDA_ERR_UNSUPPORTED;
+    }
+    // 256 x 256 tiles once they fill the chip; PDA_GEMM_SPLIT_TILE=128|256 forces a form
+    static const int force = getenv("PDA_GEMM_SPLIT_TILE") ? atoi(getenv("PDA_GEMM_SPLIT_TILE")) : 0;
+    const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
+    if (force == 256 || (force != 128 && wide_blocks >= 200 && (p.chunks % 2 == 0 || p.chunks >= 5))) {
+        static const bool ok = hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   pda::GW_SLOTS * pda::GW_SLOT * 16) == hipSuccess;
+        if (ok) {
+            hipLaunchKernelGGL(pda::gemm_split_wide_kernel, dim3((unsigned)wide_blocks), dim3(512), pda::GW_SLOTS * pda::GW_SLOT * 16,
+                               (hipStream_t)stream, p);
+            return pda::check_launch("pda_gemm_split");
+        }
     }
     hipLaunchKernelGGL(pda::gemm_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return pda::check_launch("pda_gemm_split");

@@ -220,6 +220,100 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
     }
 }
 
+// ---- narrow layers (M, N <= 64): an HBM-bound streaming reduction --------------------------------------------------
+// The set-abstraction MLPs of layer 0 (4 -> 16 -> 16 -> 32, 4 -> 32 -> 32 -> 64 over 0.5-1 M tokens) and the position MLPs
+// (12 -> 32 -> 64) have weight gradients with a 16..64-wide output and a reduction over up to a million tokens; the
+// library runs them 3-7x off the time their 40-400 MB of operands need to stream (0.1-0.2 ms each, 1.4 ms per step).
+// Here a wave streams token pairs straight into the operands of v_mfma_f32_32x32x2_f32 (lane = column, lane half = the
+// token of the pair: 128 contiguous bytes per half-wave and row), eight pairs in flight, and keeps the whole N x M product
+// in NT x MT accumulator tiles; the four waves of a workgroup are summed through LDS, the workgroups by the fixed-order
+// second stage above.  Columns beyond M / N load zeros.
+constexpr int WS_UNROLL = 8;
+constexpr int WS_MAX_SLICES = 1024;
+
+template <int NT, int MT>
+__global__ __launch_bounds__(256) void wgrad_skinny_kernel(const float* __restrict__ X, const float* __restrict__ G,
+                                                           float* __restrict__ part_w, float* __restrict__ part_b, int64_t T, int M,
+                                                           int N, int64_t KS) {
+    __shared__ float red[NT * MT * 1024 + 64 * NT];
+    const int tid = threadIdx.x, lane = lane_id(), w = wave_id();
+    const int i = lane & 31, h = lane >> 5;
+    const int64_t t_begin = (int64_t)blockIdx.x * KS, t_end = (t_begin + KS < T) ? t_begin + KS : T;
+    f32x16 acc[NT][MT];
+    float sb[NT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) {
+        sb[a] = 0.f;
+#pragma unroll
+        for (int b = 0; b < MT; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    }
+    bool gcol[NT], xcol[MT];
+#pragma unroll
+    for (int a = 0; a < NT; ++a) gcol[a] = a * 32 + i < N;
+#pragma unroll
+    for (int b = 0; b < MT; ++b) xcol[b] = b * 32 + i < M;
+    // wave w takes the pairs w, w + 4, ... of the slice, WS_UNROLL pairs per trip
+    for (int64_t t0 = t_begin + 2 * w; t0 < t_end; t0 += 8 * WS_UNROLL) {
+        float ga[WS_UNROLL][NT], xb[WS_UNROLL][MT];
+#pragma unroll
+        for (int u = 0; u < WS_UNROLL; ++u) {
+            const int64_t t = t0 + 8 * u + h;
+            const bool ok = t < t_end;
+#pragma unroll
+            for (int a = 0; a < NT; ++a) ga[u][a] = (ok && gcol[a]) ? G[t * N + a * 32 + i] : 0.f;
+#pragma unroll
+            for (int b = 0; b < MT; ++b) xb[u][b] = (ok && xcol[b]) ? X[t * M + b * 32 + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < WS_UNROLL; ++u)
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+                sb[a] += ga[u][a];
+#pragma unroll
+                for (int b = 0; b < MT; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(ga[u][a], xb[u][b], acc[a][b], 0, 0, 0);
+            }
+    }
+    // workgroup sum in wave order (fixed): C layout of a tile: row n = (r & 3) + 8 (r >> 2) + 4 h, column m = i
+    for (int turn = 0; turn < 4; ++turn) {
+        if (w == turn) {
+#pragma unroll
+            for (int a = 0; a < NT; ++a) {
+#pragma unroll
+                for (int b = 0; b < MT; ++b)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float* d = red + ((a * MT + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + i;
+                        *d = turn == 0 ? acc[a][b][r] : *d + acc[a][b][r];
+                    }
+                float* d = red + NT * MT * 1024 + a * 64 + lane;
+                *d = turn == 0 ? sb[a] : *d + sb[a];
+            }
+        }
+        __syncthreads();
+    }
+    float* pw = part_w + (size_t)blockIdx.x * N * M;
+    for (int e = tid; e < NT * MT * 1024; e += 256) {
+        const int tile = e >> 10, n = (tile / MT) * 32 + ((e >> 5) & 31), m = (tile % MT) * 32 + (e & 31);
+        if (n < N && m < M) pw[n * M + m] = red[e];
+    }
+    if (part_b) {
+        for (int n = tid; n < N; n += 256) {
+            const int o = NT * MT * 1024 + (n >> 5) * 64 + (n & 31);
+            part_b[(size_t)blockIdx.x * N + n] = red[o] + red[o + 32];
+        }
+    }
+}
+
+static bool wgrad_is_skinny(int M, int N) { return M <= 64 && N <= 64; }
+static void wgrad_skinny_plan(int64_t T, int& S, int64_t& KS) {
+    int64_t s = T / 512 > 0 ? T / 512 : 1;                 // at least 512 token rows (64 pairs per wave) per workgroup
+    if (s > WS_MAX_SLICES) s = WS_MAX_SLICES;
+    KS = divup64(divup64(T, s), 8) * 8;
+    S = (int)divup64(T, KS);
+}
+
 static void wgrad_plan(int64_t T, int M, int N, int& tiles_m, int& tiles_n, int& S, int64_t& KS) {
     tiles_m = divup(M, WG_TILE); tiles_n = divup(N, WG_TILE);
     const int tiles = tiles_m * tiles_n;
@@ -237,7 +331,8 @@ PDA_API int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, 
     if (tokens <= 0 || in_features <= 0 || out_features <= 0) return 0;
     int tm, tn, S;
     int64_t KS;
-    pda::wgrad_plan(tokens, in_features, out_features, tm, tn, S, KS);
+    if (pda::wgrad_is_skinny(in_features, out_features)) pda::wgrad_skinny_plan(tokens, S, KS);
+    else pda::wgrad_plan(tokens, in_features, out_features, tm, tn, S, KS);
     return (int64_t)S * ((int64_t)in_features * out_features + out_features) * (int64_t)sizeof(float);
 }
 
@@ -250,11 +345,27 @@ PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_
     PDA_REQUIRE((((uintptr_t)x | (uintptr_t)grad_out) & 15) == 0, "pda_linear_wgrad: x / grad_out must be 16-byte aligned");
     int tm, tn, S;
     int64_t KS;
+    hipStream_t st = (hipStream_t)stream;
+    if (pda::wgrad_is_skinny(M, N)) {
+        pda::wgrad_skinny_plan(tokens, S, KS);
+        float* pw = (float*)scratch;
+        float* pb = grad_bias ? pw + (size_t)S * N * M : (float*)nullptr;
+        const int nt = N > 32 ? 2 : 1, mt = M > 32 ? 2 : 1;
+#define PDA_WS_CASE(A, B) hipLaunchKernelGGL((pda::wgrad_skinny_kernel<A, B>), dim3(S), dim3(256), 0, st, x, grad_out, pw, pb, tokens, M, N, KS)
+        if (nt == 1 && mt == 1) PDA_WS_CASE(1, 1);
+        else if (nt == 1) PDA_WS_CASE(1, 2);
+        else if (mt == 1) PDA_WS_CASE(2, 1);
+        else PDA_WS_CASE(2, 2);
+#undef PDA_WS_CASE
+        const int64_t nm = (int64_t)N * M;
+        hipLaunchKernelGGL(pda::wgrad_reduce_kernel, dim3((unsigned)pda::divup64(nm, 64)), dim3(1024), 0, st, pw, pb, grad_weight,
+                           grad_bias, S, nm, N);
+        return pda::check_launch("pda_linear_wgrad");
+    }
     pda::wgrad_plan(tokens, M, N, tm, tn, S, KS);
     const int nblocks = S * tm * tn;
     float* part_w = (float*)scratch;
     float* part_b = part_w + (size_t)S * N * M;
-    hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pda::wgrad_kernel, dim3(pda::divup(nblocks, 8) * 8), dim3(256), 0, st, x, grad_out, part_w,
                        grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks);
     const int64_t nm = (int64_t)N * M;

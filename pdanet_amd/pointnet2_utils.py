@@ -469,7 +469,11 @@ class LinearLongTokens(Function):
             return False
         n_out, n_in = weight.shape
         tokens = x.numel() // max(1, x.shape[-1])
-        if n_out % 4 or n_in % 4 or min(n_out, n_in) < 128 or tokens < LinearLongTokens.MIN_TOKENS:
+        if n_out % 4 or n_in % 4:
+            return False
+        if max(n_out, n_in) <= 64:       # narrow layers: the streaming form (wgrad_skinny_kernel), 3-7x the library
+            return tokens >= 8192
+        if min(n_out, n_in) < 128 or tokens < LinearLongTokens.MIN_TOKENS:
             return False
         return n_out * n_in <= 256 * 768 or (n_out * n_in <= 512 * 512 and tokens >= 65536)
 
@@ -556,12 +560,16 @@ def _split_gemm_ok(x2d, k):
 def _gemm_nt(x2d, w, bias=None, relu=False):
     """relu?(x2d (T, K) @ w (N, K)^T + bias) in f32."""
     n_out, k = w.shape
-    if _split_gemm_ok(x2d, k) and w.dtype == torch.float32:
+    if _split_gemm_ok(x2d, k) and w.dtype == torch.float32 and n_out >= 128:
         x2d = x2d.contiguous()
         T = x2d.shape[0]
         y = torch.empty((T, n_out), dtype=torch.float32, device=x2d.device)
         wf = pointnet2.linear_split_pack(w.detach().contiguous(), n_out, k)
-        pointnet2.gemm_split(x2d, wf, None if bias is None else bias.detach().contiguous(), y, T, k, n_out, relu=relu)
+        bias = None if bias is None else bias.detach().contiguous()
+        if k <= 256 and n_out % 128 == 0 and n_out <= 2048:      # short K: the rows-in-registers form is ahead (BASELINE.md 4)
+            pointnet2.linear_split(x2d, wf, bias, y, T, k, n_out, relu=relu)
+        else:
+            pointnet2.gemm_split(x2d, wf, bias, y, T, k, n_out, relu=relu)
         return y
     if relu and bias is not None:
         return torch._addmm_activation(bias, x2d, w.t())
@@ -572,12 +580,15 @@ def _gemm_nt(x2d, w, bias=None, relu=False):
 def _gemm_nn(g2d, w, acc=None):
     """g2d (T, N) @ w (N, K) [+ acc, in place: acc is owned by the caller] in f32: the input gradient of y = x w^T."""
     n, k_out = w.shape
-    if _split_gemm_ok(g2d, n) and w.dtype == torch.float32:
+    if _split_gemm_ok(g2d, n) and w.dtype == torch.float32 and k_out >= 128:
         g2d = g2d.contiguous()
         T = g2d.shape[0]
         y = acc if acc is not None else torch.empty((T, k_out), dtype=torch.float32, device=g2d.device)
         wf = pointnet2.linear_split_pack(w.detach().contiguous(), k_out, n, transposed_source=True)
-        pointnet2.gemm_split(g2d, wf, None, y, T, n, k_out, accumulate=acc is not None)
+        if acc is None and n <= 256 and k_out % 128 == 0 and k_out <= 2048:
+            pointnet2.linear_split(g2d, wf, None, y, T, n, k_out)
+        else:
+            pointnet2.gemm_split(g2d, wf, None, y, T, n, k_out, accumulate=acc is not None)
         return y
     if acc is not None:
         return acc.addmm_(g2d, w)
@@ -856,7 +867,10 @@ def _lin_cols(x2, weight, y, T, k, n_out, transposed):
     """y (T, n_out) = x2 (T, k) W'^T with W' = weight (n_out, k), or weight^T when `transposed` (weight is (k, n_out))."""
     if SPLIT_GEMM:
         wf = pointnet2.linear_split_pack(weight, n_out, k, transposed_source=transposed)
-        _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out))
+        if k <= 256:
+            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out))
+        else:
+            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.gemm_split(x2, wf, None, y, T, k, n_out))
     else:
         wf = pointnet2.linear_cols_pack(weight, n_out, k, transposed_source=transposed)
         _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(x2, wf, y, T, k, n_out))
@@ -1083,7 +1097,7 @@ def position_mlp_ragged(layers, rppe, plan):
     x = rppe.reshape(-1, rppe.shape[-1]).index_select(0, plan.rowmap)        # (U, 12)
     count = plan.groups * plan.nsample
     for conv, bn in ((layers[0], layers[1]), (layers[3], layers[4])):
-        x = torch.nn.functional.linear(x, conv.weight.flatten(1))
+        x = linear(x, conv.weight.flatten(1), None)
         rm, rv = (bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None)
         bump_bn_counter(bn)
         x = BatchNormReLUWeighted.apply(x, bn.weight, bn.bias, rm, rv, bn.eps, bn.momentum, plan.roww, count)
@@ -1096,8 +1110,8 @@ def _wgrad_ragged(x2d, g2d, weight, want_bias):
     csrc/wgrad.hip reaches 60-115 (profiles/r02_gemm_probe.txt); below ~8k tokens the library is ahead."""
     n_out, n_in = weight.shape
     tokens = x2d.shape[0]
-    if (LINEAR_WGRAD_KERNEL and tokens >= 8192 and min(n_out, n_in) >= 128 and n_out % 4 == 0 and n_in % 4 == 0
-            and x2d.dtype == torch.float32 and g2d.dtype == torch.float32):
+    if (LINEAR_WGRAD_KERNEL and tokens >= 8192 and (min(n_out, n_in) >= 128 or max(n_out, n_in) <= 64) and n_out % 4 == 0
+            and n_in % 4 == 0 and x2d.dtype == torch.float32 and g2d.dtype == torch.float32):
         gw = torch.empty_like(weight)
         gb = torch.empty((n_out,), dtype=torch.float32, device=x2d.device) if want_bias else None
         pointnet2.linear_wgrad(x2d.contiguous(), g2d.contiguous(), gw, gb, tokens, n_in, n_out)

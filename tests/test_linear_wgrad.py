@@ -9,7 +9,10 @@ pytestmark = pytest.mark.gpu
 
 @pytest.mark.parametrize("tokens,n_in,n_out,bias", [(32768, 256, 128, True), (40000, 12, 32, False), (131072, 512, 1536, True),
                                                      (33000, 260, 256, False), (65536, 16, 8, True), (262144, 128, 256, True),
-                                                     (50000, 64, 4, True), (300, 32, 64, True)])
+                                                     (50000, 64, 4, True), (300, 32, 64, True),
+                                                     # wgrad_skinny_kernel: the layer-0 and position-MLP shapes, ragged token counts
+                                                     (1048576, 4, 32, True), (1048576, 32, 64, True), (524288, 16, 16, False),
+                                                     (32307, 12, 32, True), (64394, 64, 64, True), (8193, 36, 60, True)])
 def test_gradients(tokens, n_in, n_out, bias):
     from pdanet_amd import pointnet2_utils as pu
     torch.manual_seed(tokens % 1000 + n_in)
@@ -24,7 +27,7 @@ def test_gradients(tokens, n_in, n_out, bias):
     # an f32 fmaf chain, relative to sum |x||w| -- a second f32 GEMM of another summation order is not the yardstick
     xd, wd = x.detach().double(), w.detach().double()
     y_ref = xd @ wd.t() + (b.detach().double() if bias else 0)
-    assert ((y.double() - y_ref).abs() / (xd.abs() @ wd.abs().t() + 1e-30)).max().item() < 2e-6
+    assert ((y.double() - y_ref).abs() / (xd.abs() @ wd.abs().t() + (b.detach().double().abs() if bias else 0) + 1e-30)).max().item() < 2e-6
     assert (g[1].double() - gw_ref).abs().max().item() < 3e-5 * gw_ref.abs().max().item()
     assert ((g[0].double() - go.double() @ wd).abs() / (go.double().abs() @ wd.abs() + 1e-30)).max().item() < 2e-6
     if bias:
@@ -36,7 +39,9 @@ def test_dispatch_threshold_and_views():
     from pdanet_amd import pointnet2_utils as pu
     conv = torch.nn.Conv2d(128, 256, 1, bias=False).cuda()
     x = torch.randn(2, 4096, 16, 128, device="cuda", requires_grad=True)       # 131072 tokens
-    assert not pu.LinearLongTokens.supported(torch.randn(131072, 32, device="cuda"), torch.randn(64, 32, device="cuda"))
+    assert pu.LinearLongTokens.supported(torch.randn(131072, 32, device="cuda"), torch.randn(64, 32, device="cuda"))      # narrow: streaming form
+    assert not pu.LinearLongTokens.supported(torch.randn(131072, 32, device="cuda"), torch.randn(96, 32, device="cuda"))  # in between: library
+    assert not pu.LinearLongTokens.supported(torch.randn(4096, 32, device="cuda"), torch.randn(64, 32, device="cuda"))
     assert pu.LinearLongTokens.supported(x, conv.weight.flatten(1))
     assert not pu.LinearLongTokens.supported(x[:, :100], conv.weight.flatten(1))     # 3200 tokens: library path
     y = pu.linear(x, conv.weight.flatten(1), None)
