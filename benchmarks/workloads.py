@@ -181,8 +181,9 @@ class KernelTimers:
         from pdanet_amd import pointnet2_utils as pu
         split = bool(getattr(pu, "SPLIT_GEMM", False))
         if split:
-            util = pmc_record("mfma_util", "pda::lin_split_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns")
-            kern, note = "lin_split_kernel + lin_cols_kernel<gather>", (
+            util = (pmc_record("mfma_util", "pda::gemm_split_wide_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns")
+                    or pmc_record("mfma_util", "pda::lin_split_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns"))
+            kern, note = "gemm_split_wide_kernel (K = 512) + lin_split_kernel (K = 256) + lin_cols_kernel<gather>", (
                 "f32 contractions on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 terms (x = h + m + l "
                 "exactly; 6 of 9 products kept, error below the f32 fmaf chain's: tests/test_gemm_split.py); peak = the f32 "
                 "MFMA peak the same contraction had before (a fraction above 1 means faster than any f32-input MFMA kernel "

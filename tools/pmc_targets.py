@@ -7,6 +7,7 @@
   sa_mlp       fused SA scale 259->256->512->512, ns 64     -> mfma_util["pda::sa_mlp_kernel ..."]
   lin_cols     training-form contraction 512->512, 131072 tokens -> mfma_util["pda::lin_cols_kernel ..."]
   lin_split    the same contraction on the split-bf16 kernel     -> mfma_util["pda::lin_split_kernel ..."]
+  gemm_split   the same on the LDS-tiled split-bf16 kernel       -> mfma_util["pda::gemm_split_wide_kernel ..."]
 Inputs are the bench's (synth scene config_id 2, distribution L)."""
 import sys
 
@@ -51,6 +52,13 @@ elif target == "lin_cols":
     wf = ext.linear_cols_pack(w, n, k)
     for _ in range(reps):
         ext.linear_cols(x, wf, y, t, k, n)
+elif target == "gemm_split":
+    # the LDS-tiled split-bf16 GEMM (256 x 256 tiles): ONCE layer 5, scale 3, layer 3 forward (131072 tokens, 512 -> 512)
+    t, k, n = 131072, 512, 512
+    x, w, y = torch.randn(t, k, device=dev), torch.randn(n, k, device=dev), torch.empty(t, n, device=dev)
+    wf = ext.linear_split_pack(w, n, k)
+    for _ in range(reps):
+        ext.gemm_split(x, wf, None, y, t, k, n)
 elif target == "lin_split":
     t, k, n = 131072, 512, 512
     x, w, y = torch.randn(t, k, device=dev), torch.randn(n, k, device=dev), torch.empty(t, n, device=dev)
