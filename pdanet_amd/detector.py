@@ -124,7 +124,7 @@ class IASSD(nn.Module):
     def _forward_graphed_tail(self, batch_dict, i0):
         bb = self.backbone_3d
         with bb.bn_counters():
-            st = bb._begin(batch_dict)
+            st = bb._begin(batch_dict, first_graphed=i0)
             for i in range(i0):
                 bb._run_layer(i, st)
         sa, cls_pred = st['sa_ins_preds'], st['li_cls_pred']
