@@ -54,3 +54,46 @@ def test_split_gemm_exact_on_integers_and_refuses_other_shapes():
         ext.linear_split(x[:, :100].contiguous(), ext.linear_split_pack(w, N, K), None, y, T, 100, N)
     with pytest.raises(_lib.PdaError):
         ext.linear_split(x, ext.linear_split_pack(w, N, K), None, y, T, K, 200)
+
+
+@pytest.mark.parametrize("T,K,N", [(1, 32, 1), (100, 64, 100), (4099, 32, 259), (5000, 768, 256), (12979, 256, 259),   # 128 x 128 tiles
+                                   (33000, 512, 512), (64394, 1536, 512), (40000, 512, 1536), (70001, 256, 640)])   # 256 x 256 tiles
+def test_tiled_split_gemm(T, K, N):
+    """pda_gemm_split (gemm_split_kernel / gemm_split_wide_kernel): any K % 32 == 0, any N, ragged T; bias, fused ReLU and the
+    accumulate form; the same f32-grade bar as above."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    g = torch.Generator("cuda").manual_seed(T + K + N)
+    x = torch.randn(T, K, device="cuda", generator=g) * torch.exp(2 * torch.randn(T, K, device="cuda", generator=g))
+    w = torch.randn(N, K, device="cuda", generator=g)
+    bias = torch.randn(N, device="cuda", generator=g)
+    wf = ext.linear_split_pack(w, N, K)
+    y = torch.full((T, N), float("nan"), device="cuda")
+    ext.gemm_split(x, wf, bias, y, T, K, N)
+    assert torch.isfinite(y).all()
+    e, e_lib = _rel_err(y, x, w, bias), _rel_err(torch.nn.functional.linear(x, w, bias), x, w, bias)
+    assert e < 4e-6 and e < 3 * e_lib + 1e-7, (e, e_lib)      # f32 accumulation over K up to 1536: the library's own error level
+    # dX = dY W through the transposed pack, accumulated onto an existing tensor
+    gy = torch.randn(T, N, device="cuda", generator=g)
+    if N % 32 == 0:
+        base = torch.randn(T, K, device="cuda", generator=g)
+        acc = base.clone()
+        ext.gemm_split(gy, ext.linear_split_pack(w, K, N, transposed_source=True), None, acc, T, N, K, accumulate=True)
+        ref = base.double() + gy.double() @ w.double()
+        scale = base.double().abs() + gy.double().abs() @ w.double().abs()
+        assert ((acc.double() - ref).abs() / scale).max().item() < 4e-6
+    y2 = torch.empty(T, N, device="cuda")
+    ext.gemm_split(x, wf, None, y2, T, K, N, relu=True)
+    assert (y2 >= 0).all() and _rel_err(torch.where(y2 > 0, y2, (y - bias).clamp(max=0)), x, w, None) < 4e-6
+
+
+def test_narrow_and_short_problems_stay_on_the_library():
+    """pointnet2_utils._gemm_nt / _gemm_nn: below 4096 tokens, for outputs narrower than 128 or K not a multiple of 32 the
+    library GEMM runs (and gives the same numbers to f32 rounding)."""
+    from pdanet_amd import pointnet2_utils as pu
+    g = torch.Generator("cuda").manual_seed(3)
+    for T, K, N in ((100, 64, 256), (10000, 48, 256), (10000, 64, 32), (10000, 64, 256)):
+        x = torch.randn(T, K, device="cuda", generator=g); w = torch.randn(N, K, device="cuda", generator=g); b = torch.randn(N, device="cuda", generator=g)
+        y = pu._gemm_nt(x, w, b, relu=True)
+        assert torch.allclose(y, torch.relu(torch.nn.functional.linear(x, w, b)), atol=1e-4, rtol=1e-4)
+        gx = pu._gemm_nn(y, w)
+        assert torch.allclose(gx, y @ w, atol=2e-3, rtol=1e-4)
