@@ -12,6 +12,7 @@ per forward, :131-137), and the D-FPS of layer k+1 can be launched on a side str
 depends only on coordinates (see `prefetch_fps`).
 """
 import contextlib
+import os
 
 import torch
 import torch.nn as nn
@@ -101,9 +102,13 @@ class IASSD_Backbone(nn.Module):
             plan.append(i)
         if not plan or not xyz.is_cuda:
             return {}
-        if xyz.shape[1] > 24576:
-            # the multi-workgroup FPS form (csrc/fps.hip) wants its K workgroups per scene resident together: keep
-            # it on the main stream, in program order, instead of racing other kernels for CUs on a side stream
+        if xyz.shape[1] > 24576 and os.environ.get("PDA_COOP_FPS_SIDE_STREAM", "1") == "0":
+            # The multi-workgroup FPS form (csrc/fps.hip, n > 24576) exchanges winners between the K workgroups of a scene.
+            # On the side stream its workgroups share the chip with the main stream's kernels and may become resident late;
+            # that cannot deadlock (the main stream's workgroups finish on their own and free their CUs; every poll is
+            # bounded; a time-out is recovered on the device and counted: pda_fps_coop_timeouts).  Config 5 (65536 pts,
+            # B = 8): 32 of 256 CUs busy for 33 ms when it runs in program order, hidden under the previous iteration's
+            # backward here: 105 -> 73 ms per iteration, no time-out in any run.  PDA_COOP_FPS_SIDE_STREAM=0: program order.
             return {}
         if self._side_stream is None or self._side_stream.device != xyz.device:
             self._side_stream = torch.cuda.Stream(device=xyz.device)

@@ -37,3 +37,24 @@ def test_forced_exchange_timeout_is_counted_and_recovered(ext, oracle):
     idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
     assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
     assert ext.fps_coop_timeouts() == 0
+
+
+def test_cooperative_fps_on_the_side_stream_gives_the_same_backbone_output(monkeypatch):
+    """backbone._presample runs the multi-workgroup FPS (65536-point scenes, config 5) on the sampling side stream, next to
+    the main stream's kernels: same centres and features as in program order, and no exchange timed out."""
+    from pdanet_amd import backbone as bbm, pointnet2_batch_cuda as ext, synth
+    torch.manual_seed(3)
+    model = bbm.build_backbone("once_pda_ssd.yaml")[0].cuda().eval()
+    pts = torch.from_numpy(synth.batch_points(2, 65536, config_id=5, dist="L", dataset="once")).cuda()
+    torch.cuda.synchronize()
+    outs = {}
+    ext.fps_coop_timeouts(reset=True)
+    with torch.no_grad():
+        for flag in ("0", "1"):
+            monkeypatch.setenv("PDA_COOP_FPS_SIDE_STREAM", flag)
+            for _ in range(2):      # the second call runs with a warm allocator / streams
+                bd = model({'batch_size': 2, 'points': pts, 'inputs_resident': True})     # pts IS resident (no copy in flight)
+            outs[flag] = (bd['centers'].clone(), bd['centers_features'].clone(), bd['encoder_xyz'][1].clone())
+    assert ext.fps_coop_timeouts() == 0
+    for a, b in zip(outs["0"], outs["1"]):
+        assert torch.equal(a, b)
