@@ -247,6 +247,31 @@ int64_t pda_nms_mask_words(int n);
 int pda_nms_bev(const float *boxes, const int32_t *num_valid, int64_t *keep, int32_t *num_keep,
                 uint64_t *mask_scratch, int b, int n, float thresh, int normal, pda_stream_t stream);
 
+/* ---- loss terms of the IA-SSD head, one launch each: the term AND its gradient (csrc/head_loss.hip) --------------------------
+ * Replace the elementwise torch chains of IASSD_head.py:525-735, :1239-1321 and loss_utils.py:75-194, :340-363.  All tensors
+ * row-major f32 unless noted; labels int64; every `grad` output has the layout of the prediction it belongs to and is written
+ * completely; the autograd node multiplies it by the incoming scalar.
+ *   pda_head_cls_loss:    out2 = {scale * sum_rows w_row * mean_c bce(x, t), #positives}; w_row = [label >= 0] / max(#pos, 1),
+ *                         t = [label == c + 1] * soft_row (soft may be NULL = 1); the C logits sit in columns col0 .. col0+C-1
+ *                         of rows of row_stride floats.
+ *   pda_head_centerness:  generate_center_ness_mask (:795-817); centers (n, 4) [bs, x, y, z], gt (n, 8).
+ *   pda_head_box_loss:    get_center_box_binori_layer_loss; preds (n, 6 + 2 bins), labels (n, 8); out4 = {total, xyzwhl,
+ *                         ori_bin * dir_weight, ori_res}; code_weights 6 floats or NULL.
+ *   pda_head_vote_loss:   mode 0 get_contextual_vote_loss (key = class label of the point), mode 1 _ver2 (key = box index, -1
+ *                         none; b scenes of n / b points, `boxes` boxes per scene); origin, offsets, grad (n, 4) [bs, x, y, z].
+ *   pda_head_corner_loss: get_corner_layer_loss incl. the decode of PointResidual_BinOri_Coder (mean_size (num_class, 3) or
+ *                         NULL); NaN without positive centres, like the reference. */
+int pda_head_cls_loss(const float *preds, int row_stride, int col0, int num_class, const int64_t *labels, const float *soft,
+                      int64_t n, float scale, float *out2, float *grad, pda_stream_t stream);
+int pda_head_centerness(const float *centers, const float *gt, const int64_t *labels, float *out, int64_t n, pda_stream_t stream);
+int pda_head_box_loss(const float *preds, const float *labels, const int64_t *cls_labels, const float *code_weights, float beta,
+                      int bins, float dir_weight, float box_weight, int64_t n, float *out4, float *grad, pda_stream_t stream);
+int pda_head_vote_loss(int mode, const float *origin, const float *offsets, const int64_t *key, const float *gt, int b, int boxes,
+                       int num_class, float weight, int64_t n, float *out1, float *grad, pda_stream_t stream);
+int pda_head_corner_loss(const float *box_preds, const float *centers, const float *cls_preds, int num_class, const float *gt,
+                         const int64_t *cls_labels, const float *mean_size, int bins, float weight, int64_t n, float *out1,
+                         float *grad_box, float *grad_centers, pda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

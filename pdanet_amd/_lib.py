@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -100,6 +100,11 @@ SIGNATURES = {
     "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_assign_point_targets": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_sa_gaussian_mask": [_vp, _i, _i, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "pda_head_cls_loss": [_vp, _i, _i, _i, _vp, _vp, ctypes.c_int64, _f, _vp, _vp, _vp],
+    "pda_head_centerness": [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "pda_head_box_loss": [_vp, _vp, _vp, _vp, _f, _i, _f, _f, ctypes.c_int64, _vp, _vp, _vp],
+    "pda_head_vote_loss": [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, ctypes.c_int64, _vp, _vp, _vp],
+    "pda_head_corner_loss": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _f, ctypes.c_int64, _vp, _vp, _vp, _vp],
     "pda_boxes_overlap_bev": [_vp, _vp, _vp, _i, _i, _vp],
     "pda_boxes_iou_bev": [_vp, _vp, _vp, _i, _i, _vp],
     "pda_nms_mask_words": [_i],

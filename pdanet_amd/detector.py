@@ -26,7 +26,11 @@ class _HeadLoss(nn.Module):
               'centers_origin': centers_origin, 'ctr_offsets': ctr_offsets, 'gt_boxes': gt_boxes,
               'sa_ins_preds': [next(it) if has else [] for has in self.sa_slots],
               'encoder_coords': list(rest[n_sa:n_sa + self.n_coords])}
-        self.head(bd)
+        keep, self.head.decode_in_training = self.head.decode_in_training, False
+        try:
+            self.head(bd)
+        finally:
+            self.head.decode_in_training = keep
         loss, tb = self.head.get_loss()
         if self.keys is None:
             self.keys = [k for k, v in tb.items() if isinstance(v, torch.Tensor)]
@@ -60,7 +64,11 @@ class _TailLoss(nn.Module):
             for i in range(i0, len(bb.SA_modules)):
                 bb._run_layer(i, st)
             bb._finish(bd, st)
-            self.head(bd)
+            keep, self.head.decode_in_training = self.head.decode_in_training, False
+            try:
+                self.head(bd)
+            finally:
+                self.head.decode_in_training = keep
         loss, tb = self.head.get_loss()
         if self.keys is None:
             self.keys = [k for k, v in tb.items() if isinstance(v, torch.Tensor)]
@@ -73,6 +81,7 @@ class IASSD(nn.Module):
         self.backbone_3d = IASSD_Backbone(model_cfg["BACKBONE_3D"], num_class=num_class, input_channels=num_point_features)
         self.point_head = IASSD_Head(num_class=num_class, input_channels=self.backbone_3d.num_point_features,
                                      model_cfg=model_cfg["POINT_HEAD"])
+        self.point_head.decode_in_training = False     # the training iteration never reads the decoded boxes (iassd_head.forward)
         self.module_list = [self.backbone_3d, self.point_head]
         self.model_cfg, self.num_class = model_cfg, num_class
         # graph_head: replay the head + losses (target assignment, ~400 small launches forward and backward, static

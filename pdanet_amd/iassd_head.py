@@ -22,6 +22,8 @@ clusterContrastLoss member (:47); loss branches no PDA-SSD yaml selects (ver1 vo
 PointResidualCoder, focal / binary-CE variants).
 """
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -34,6 +36,12 @@ def _get(cfg, key, default=None):
 
 
 FUSED_HEAD_TARGETS = True   # csrc/head_targets.hip instead of ~20-30 elementwise launches per point set
+
+# FUSED_HEAD_LOSS: every loss term is one launch that also produces its gradient (csrc/head_loss.hip) instead of a chain of
+# elementwise torch operators (~700 launches of 2-3 us per iteration, forward and backward).  CUDA tensors only; the torch
+# formulation below stays the CPU path and the reference the kernels are tested against (tests/test_iassd_head.py).
+FUSED_HEAD_LOSS = os.environ.get("PDA_FUSED_HEAD_LOSS", "1") != "0"
+
 
 class IASSD_Head(nn.Module):  # noqa: N801
     def __init__(self, num_class, input_channels, model_cfg, predict_boxes_when_training=False, **kwargs):
@@ -69,6 +77,7 @@ class IASSD_Head(nn.Module):  # noqa: N801
                 raise NotImplementedError("%s = %s" % (key, losses_cfg[key]))
         if losses_cfg["LOSS_REG"] != "WeightedSmoothL1Loss":
             raise NotImplementedError(losses_cfg["LOSS_REG"])
+        self.decode_in_training = True      # see forward()
         self.cls_loss_func = loss_utils.WeightedClassificationLoss()
         self.ins_loss_func = loss_utils.WeightedClassificationLoss()
         self.reg_loss_func = loss_utils.WeightedSmoothL1Loss(
@@ -200,8 +209,14 @@ class IASSD_Head(nn.Module):  # noqa: N801
         if self.training:
             ret.update(self.assign_targets(batch_dict))
         loss_cfg = self.model_cfg["LOSS_CONFIG"]
-        if (not self.training or self.predict_boxes_when_training or _get(loss_cfg, "CORNER_LOSS_REGULARIZATION", False)
-                or _get(loss_cfg, "CENTERNESS_REGULARIZATION", False) or _get(loss_cfg, "IOU3D_REGULARIZATION", False)):
+        # The reference decodes the boxes in training whenever a regulariser is configured (:1379-1387); only its corner loss
+        # reads them, and the fused corner-loss kernel decodes them itself.  `decode_in_training = False` (set by
+        # detector.IASSD around its graphed head) skips the ~30 launches of the unused decode.
+        regularised = (_get(loss_cfg, "CORNER_LOSS_REGULARIZATION", False) or _get(loss_cfg, "CENTERNESS_REGULARIZATION", False)
+                       or _get(loss_cfg, "IOU3D_REGULARIZATION", False))
+        skip = (self.training and not self.predict_boxes_when_training and not self.decode_in_training and FUSED_HEAD_LOSS
+                and feats.is_cuda and not _get(loss_cfg, "IOU3D_REGULARIZATION", False))
+        if (not self.training or self.predict_boxes_when_training or regularised) and not skip:
             point_cls_preds, point_box_preds = self.generate_predicted_boxes(centers[:, 1:4], cls_preds, box_preds)
             batch_dict['batch_cls_preds'], batch_dict['batch_box_preds'] = point_cls_preds, point_box_preds
             batch_dict['box_iou3d_preds'] = None
@@ -240,6 +255,12 @@ class IASSD_Head(nn.Module):  # noqa: N801
         smooth-L1(vote, mean vote of the instance)] / #points, then the mean over instances."""
         r = self.forward_ret_dict
         idx, gt = r['center_origin_box_idxs_of_pts'], r['gt_box_of_center_origin']
+        if FUSED_HEAD_LOSS and gt.is_cuda and self._bs * self._num_boxes <= 2048:
+            loss = roiaware_pool3d_utils.head_vote_loss(1, r['centers_origin'].detach().contiguous(), r['ctr_offsets'], idx.contiguous(),
+                                                        gt.contiguous(), self._bs, self._num_boxes, self.num_class,
+                                                        self._weights()['vote_weight'])
+            tb_dict['vote_loss_ver2'] = loss.detach()
+            return loss
         pred = r['centers_origin'][:, 1:4] + r['ctr_offsets'][:, 1:4]
         B, S = self._bs, self._num_boxes                      # segment = scene * (boxes per scene) + box index
         scene = torch.arange(B, device=idx.device).repeat_interleave(idx.shape[0] // B)
@@ -263,6 +284,12 @@ class IASSD_Head(nn.Module):  # noqa: N801
         """:525-548.  Mean over the classes present of the mean smooth-L1 between votes and box centres."""
         r = self.forward_ret_dict
         labels, gt = r['center_origin_cls_labels'], r['gt_box_of_center_origin']
+        if FUSED_HEAD_LOSS and gt.is_cuda:
+            loss = roiaware_pool3d_utils.head_vote_loss(0, r['centers_origin'].detach().contiguous(), r['ctr_offsets'], labels.contiguous(),
+                                                        gt.contiguous(), self._bs, self._num_boxes, self.num_class,
+                                                        self._weights()['vote_weight'])
+            tb_dict['center_origin_loss_reg'] = loss.detach()
+            return loss
         pred = r['centers_origin'][:, 1:4] + r['ctr_offsets'][:, 1:4]
         l = F.smooth_l1_loss(pred, gt[:, 0:3], reduction='none').sum(-1)
         total, present = 0, 0
@@ -293,6 +320,13 @@ class IASSD_Head(nn.Module):  # noqa: N801
         r = self.forward_ret_dict
         labels = r['center_cls_labels'].view(-1)
         preds = r['center_cls_preds'].view(-1, self.num_class)
+        if FUSED_HEAD_LOSS and preds.is_cuda:
+            soft = None
+            if self.model_cfg["LOSS_CONFIG"]["CENTERNESS_REGULARIZATION"]:
+                soft = roiaware_pool3d_utils.head_centerness(r['centers'].detach().contiguous(), r['center_gt_box_of_points'].contiguous(), labels)
+            loss, n = roiaware_pool3d_utils.head_cls_loss(preds, 0, self.num_class, labels, soft, self._weights()['point_cls_weight'])
+            tb_dict.update(center_loss_cls=loss.detach(), center_pos_num=n)
+            return loss
         w, n = self._cls_weights(labels)
         targets = self._one_hot_targets(preds, labels, self.num_class)
         if self.model_cfg["LOSS_CONFIG"]["CENTERNESS_REGULARIZATION"]:
@@ -354,8 +388,14 @@ class IASSD_Head(nn.Module):  # noqa: N801
             if len(preds_l[i]) == 0:
                 ignore += 1
                 continue
-            preds = preds_l[i][..., 1:].reshape(-1, self.num_class)
             labels = labels_l[i].view(-1)
+            if FUSED_HEAD_LOSS and preds_l[i].is_cuda:
+                soft = masks[i] if 'ctr' in methods[i + 1][0] else None
+                li, n = roiaware_pool3d_utils.head_cls_loss(preds_l[i], 1, self.num_class, labels, soft, ws[i])
+                total = total + li
+                tb_dict['sa%d_loss_ins' % i], tb_dict['sa%d_pos_num' % i] = li.detach(), n
+                continue
+            preds = preds_l[i][..., 1:].reshape(-1, self.num_class)
             w, n = self._cls_weights(labels)
             targets = self._one_hot_targets(preds, labels, self.num_class)
             if 'ctr' in methods[i + 1][0]:
@@ -372,6 +412,13 @@ class IASSD_Head(nn.Module):  # noqa: N801
         r = self.forward_ret_dict
         pos = r['center_cls_labels'] > 0
         labels, preds = r['center_box_labels'], r['center_box_preds']
+        if FUSED_HEAD_LOSS and preds.is_cuda:
+            lw = self._weights()
+            loss, l_xyz, l_bin, l_res = roiaware_pool3d_utils.head_box_loss(
+                preds, labels.contiguous(), r['center_cls_labels'].view(-1), self.reg_loss_func.code_weights, self.reg_loss_func.beta,
+                self.box_coder.bin_size, _get(lw, 'dir_weight', 1.0), lw['point_box_weight'])
+            tb_dict.update(center_loss_box=loss.detach(), center_loss_box_xyzwhl=l_xyz, center_loss_box_ori_bin=l_bin, center_loss_box_ori_res=l_res)
+            return loss
         w = pos.float()
         w = w / torch.clamp(pos.sum().float(), min=1.0)
         loss_xyzwhl = self.reg_loss_func(preds[None, :, :6], labels[None, :, :6], weights=w[None]).sum()
@@ -392,6 +439,14 @@ class IASSD_Head(nn.Module):  # noqa: N801
         """:1307-1321."""
         r = self.forward_ret_dict
         pos = r['center_cls_labels'] > 0
+        if FUSED_HEAD_LOSS and r['center_box_preds'].is_cuda and isinstance(self.box_coder, box_coder_utils.PointResidual_BinOri_Coder):
+            mean = self.box_coder._mean(r['center_box_preds']) if self.box_coder.use_mean_size else None
+            loss = roiaware_pool3d_utils.head_corner_loss(r['center_box_preds'], r['centers'], r['center_cls_preds'],
+                                                          r['center_gt_box_of_points'].contiguous(), r['center_cls_labels'].view(-1),
+                                                          None if mean is None else mean.contiguous(), self.box_coder.bin_size,
+                                                          self._weights()['corner_weight'])
+            tb_dict['corner_loss_reg'] = loss.detach()
+            return loss
         per_pt = loss_utils.get_corner_loss_lidar(r['point_box_preds'][:, 0:7], r['center_gt_box_of_points'][:, 0:7])
         loss = torch.where(pos, per_pt, torch.zeros_like(per_pt)).sum() / pos.sum()
         loss = loss * self._weights()['corner_weight']

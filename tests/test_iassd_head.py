@@ -162,3 +162,31 @@ def test_fused_target_kernels_equal_the_torch_formulation(kwargs):
             iassd_head.FUSED_HEAD_TARGETS = True
     assert masks[0].shape == masks[1].shape and (masks[0] > 0).any()
     assert torch.allclose(masks[0], masks[1], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["once", "kitti"])
+def test_fused_loss_kernels_equal_the_torch_formulation(tag):
+    """csrc/head_loss.hip (one launch per loss term, gradient included) against the elementwise torch formulation of the same
+    terms: every logged value, the total, and the gradients of every input that carries one -- including the vote centres,
+    which the golden inputs hold as constants (the corner loss decodes boxes around them)."""
+    from pdanet_amd import iassd_head
+    res = {}
+    for fused in (True, False):
+        iassd_head.FUSED_HEAD_LOSS = fused
+        try:
+            gold, head, bd, leaves = _prepare(tag, "cuda")
+            bd["centers"] = bd["centers"].clone().requires_grad_(True)
+            leaves = dict(leaves, centers=bd["centers"])
+            loss, tb = _step(head, bd)
+            res[fused] = (float(loss), {k: float(v) for k, v in tb.items()}, {k: v.grad.clone() for k, v in leaves.items()})
+        finally:
+            iassd_head.FUSED_HEAD_LOSS = True
+    (lf, tf, gf), (lt, tt, gt_) = res[True], res[False]
+    assert lf == pytest.approx(lt, rel=2e-5)
+    assert set(tf) == set(tt)
+    for k in tt:
+        assert tf[k] == pytest.approx(tt[k], rel=2e-5, abs=1e-6), k
+    for k in gt_:
+        assert (gf[k] - gt_[k]).abs().max().item() <= 2e-5 * max(1.0, gt_[k].abs().max().item()), k
+    assert gf["centers"].abs().max().item() > 0
