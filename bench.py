@@ -43,8 +43,8 @@ if ROOT not in sys.path:
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--workload", default="auto")
     ap.add_argument("--batch", type=int, default=None, help="scenes per GPU (default: the yaml's 2 for ONCE, 4 for KITTI)")
     ap.add_argument("--points", type=int, default=16384)

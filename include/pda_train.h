@@ -226,6 +226,12 @@ int pda_assign_point_targets(const float *gt_boxes, const int32_t *in_box, const
 /* Soft instance labels of gauss_fun_once_topk_GT_add_same_size (IASSD_head.py:889-963): out[p] = exp(-0.5 |S d|^2) where
  * labels[p] > 0, else 0; d = offset of point p (coords + p*stride + offset: x, y, z) in the frame of its box
  * gt_of_points[p], S = diag(4/(w^2+l^2), 4/(w^2+h^2), 4/(h^2+l^2)) times 4 / 6 / 5 for classes 1 / 2 / 3. */
+/* assign_stack_targets_IASSD (IASSD_head.py:132-277) for one point set in one launch: both box queries (boxes, and boxes
+ * enlarged by extra_width[3] -- a HOST pointer), labels / box index / gathered box, and (box_labels != NULL) the box-coder
+ * targets of the foreground points.  points: rows of point_stride floats, xyz at point_offset (b * n rows, scene-major). */
+int pda_head_assign_targets(const float *points, int point_stride, int point_offset, const float *gt_boxes, const float *extra_width,
+                            int64_t *labels, int64_t *box_idx, float *gt_of_points, float *box_labels, const float *mean_size,
+                            int bins, int b, int n, int t, int mode, int single_class, pda_stream_t stream);
 int pda_sa_gaussian_mask(const float *coords, int stride, int offset, const float *gt_of_points, const int64_t *labels,
                          float *out, int64_t points, pda_stream_t stream);
 

@@ -100,6 +100,7 @@ SIGNATURES = {
     "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_assign_point_targets": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_sa_gaussian_mask": [_vp, _i, _i, _vp, _vp, _vp, ctypes.c_int64, _vp],
+    "pda_head_assign_targets": [_vp, _i, _i, _vp, ctypes.POINTER(ctypes.c_float), _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "pda_head_cls_loss": [_vp, _i, _i, _i, _vp, _vp, ctypes.c_int64, _f, _vp, _vp, _vp],
     "pda_head_centerness": [_vp, _vp, _vp, _vp, ctypes.c_int64, _vp],
     "pda_head_box_loss": [_vp, _vp, _vp, _vp, _f, _i, _f, _f, ctypes.c_int64, _vp, _vp, _vp],

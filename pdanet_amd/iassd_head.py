@@ -86,7 +86,7 @@ class IASSD_Head(nn.Module):  # noqa: N801
     # ---- target assignment ---------------------------------------------------------------------
     def assign_stack_targets_IASSD(self, points, gt_boxes, extend_gt_boxes=None, ret_box_labels=False,  # noqa: N802
                                    set_ignore_flag=True, use_ex_gt_assign=False, fg_pc_ignore=False,
-                                   binary_label=False):
+                                   binary_label=False, extra_width=None):
         """IASSD_head.py:132-277 for all scenes at once.
 
         points (B*N, 4) [bs_idx, x, y, z] scene-major, gt_boxes / extend_gt_boxes (B, T, 8).
@@ -101,6 +101,16 @@ class IASSD_Head(nn.Module):  # noqa: N801
         assert points.dim() == 2 and points.shape[1] == 4 and gt_boxes.dim() == 3 and gt_boxes.shape[2] == 8
         B, T = gt_boxes.shape[0], gt_boxes.shape[1]
         assert points.shape[0] % B == 0, "scenes must contribute equally many points"
+        if FUSED_HEAD_TARGETS and points.is_cuda and extra_width is not None and (use_ex_gt_assign or set_ignore_flag):
+            # the two box queries, the assignment and the box-coder targets in ONE launch (csrc/head_targets.hip)
+            mode = (2 if fg_pc_ignore else 1) if use_ex_gt_assign else 0
+            coder = self.box_coder
+            mean = coder._mean(gt_boxes).contiguous() if (ret_box_labels and coder.use_mean_size) else None
+            labels, idx, gt_of_pts, box_labels = roiaware_pool3d_utils.head_assign_targets(
+                points.contiguous(), gt_boxes.contiguous(), extra_width, mode, self.num_class == 1 or binary_label, mean_size=mean,
+                bins=coder.bin_size, ret_box_labels=ret_box_labels)
+            return {'point_cls_labels': labels, 'point_box_labels': box_labels, 'box_idxs_labels': idx,
+                    'gt_box_of_points': gt_of_pts}
         xyz = points[:, 1:4].reshape(B, -1, 3).contiguous()
         N = xyz.shape[1]
         if FUSED_HEAD_TARGETS and xyz.is_cuda and (use_ex_gt_assign or set_ignore_flag):
@@ -158,25 +168,29 @@ class IASSD_Head(nn.Module):  # noqa: N801
         if _get(target_cfg, 'EXTRA_WIDTH', False):
             raise NotImplementedError("TARGET_CONFIG.EXTRA_WIDTH (enlarge_box3d_for_class)")
 
+        fused = FUSED_HEAD_TARGETS and gt_boxes.is_cuda
+
         def enlarge(width):
+            if fused:
+                return None          # the fused assignment enlarges the boxes itself (extra_width)
             return box_utils.enlarge_box3d(gt_boxes.view(-1, gt_boxes.shape[-1]), extra_width=width).view(B, -1, gt_boxes.shape[-1])
 
         out = {}
         t = self.assign_stack_targets_IASSD(input_dict['centers'].detach(), gt_boxes, enlarge(target_cfg["GT_EXTRA_WIDTH"]),
-                                            set_ignore_flag=True, ret_box_labels=True)
+                                            set_ignore_flag=True, ret_box_labels=True, extra_width=target_cfg["GT_EXTRA_WIDTH"])
         out['center_cls_labels'], out['center_box_labels'] = t['point_cls_labels'], t['point_box_labels']
         out['center_gt_box_of_points'] = t['gt_box_of_points']
         if _get(target_cfg, 'INS_AWARE_ASSIGN', False):
             preds = input_dict['sa_ins_preds']
             ext = enlarge([0.5, 0.5, 0.5])
             first = self.assign_stack_targets_IASSD(input_dict['encoder_coords'][0].reshape(-1, 4).detach(), gt_boxes, ext,
-                                                    set_ignore_flag=True)            # :329-343
+                                                    set_ignore_flag=True, extra_width=[0.5, 0.5, 0.5])            # :329-343
             out['get_origin_class_label'] = [first['point_cls_labels']]
             labels, boxes, coords, idxs = [], [], [], []
             for i in range(1, len(preds)):                                            # :347-385
                 sa_xyz = input_dict['encoder_coords'][i]
                 t = self.assign_stack_targets_IASSD(sa_xyz.reshape(-1, sa_xyz.shape[-1]).detach(), gt_boxes, ext,
-                                                    set_ignore_flag=(i == 1), use_ex_gt_assign=(i >= 2))
+                                                    set_ignore_flag=(i == 1), use_ex_gt_assign=(i >= 2), extra_width=[0.5, 0.5, 0.5])
                 coords.append(sa_xyz); labels.append(t['point_cls_labels'])
                 boxes.append(t['gt_box_of_points']); idxs.append(t['box_idxs_labels'])
             out.update(sa_ins_labels=labels, sa_xyz_coords=coords, sa_gt_box_of_points=boxes, sa_box_idxs_labels=idxs)
@@ -186,7 +200,7 @@ class IASSD_Head(nn.Module):  # noqa: N801
                 raise NotImplementedError(extra["NAME"])
             pts = input_dict['centers_origin' if _get(extra, 'ASSIGN_TYPE', 'centers') == 'centers_origin' else 'centers'].detach()
             t = self.assign_stack_targets_IASSD(pts, gt_boxes, enlarge(extra["EXTRA_WIDTH"]), set_ignore_flag=True,
-                                                ret_box_labels=True, use_ex_gt_assign=True,
+                                                ret_box_labels=True, use_ex_gt_assign=True, extra_width=extra["EXTRA_WIDTH"],
                                                 fg_pc_ignore=extra["FG_PC_IGNORE"])  # :397-411
             out['center_origin_cls_labels'] = t['point_cls_labels']
             out['center_origin_box_idxs_of_pts'] = t['box_idxs_labels']

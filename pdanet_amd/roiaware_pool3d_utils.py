@@ -48,6 +48,27 @@ def assign_point_targets(gt_boxes, in_box, in_ext, mode, single_class):
     return labels, idx, gt_of
 
 
+def head_assign_targets(points, gt_boxes, extra_width, mode, single_class, mean_size=None, bins=0, ret_box_labels=False):
+    """MI355X extension (csrc/head_targets.hip): assign_stack_targets_IASSD for one point set in ONE launch.  points (B*N, 4)
+    [bs, x, y, z] scene-major, gt_boxes (B, T, 8), extra_width 3 python floats -> labels (B*N) int64, box index (B*N) int64,
+    gt_of_points (B*N, 8), box-coder targets (B*N, 8) or None."""
+    import ctypes
+    B, T = gt_boxes.shape[0], gt_boxes.shape[1]
+    P = points.shape[0]
+    N = P // B
+    dev = gt_boxes.device
+    labels = torch.empty((P,), dtype=torch.int64, device=dev)
+    idx = torch.empty((P,), dtype=torch.int64, device=dev)
+    gt_of = torch.empty((P, 8), dtype=torch.float32, device=dev)
+    box_labels = torch.empty((P, 8), dtype=torch.float32, device=dev) if ret_box_labels else None
+    ew = (ctypes.c_float * 3)(*[float(w) for w in extra_width])
+    _call("pda_head_assign_targets", gt_boxes, _chk(points, "points", F32), int(points.shape[1]), 1, _chk(gt_boxes, "gt_boxes", F32), ew,
+          _chk(labels, "labels", torch.int64), _chk(idx, "box_idx", torch.int64), _chk(gt_of, "gt_of_points", F32),
+          None if box_labels is None else _chk(box_labels, "box_labels", F32), None if mean_size is None else _chk(mean_size, "mean_size", F32),
+          int(bins), B, N, T, int(mode), int(bool(single_class)))
+    return labels, idx, gt_of, box_labels
+
+
 def sa_gaussian_mask(coords, gt_of_points, labels):
     """MI355X extension: soft instance labels (IASSD_head.py:889-963) for the points coords (P, 1+3[+...]) [bs, x, y, z, ...]
     against their boxes gt_of_points (P, 8); 0 where labels <= 0.  One launch."""

@@ -150,6 +150,14 @@ def test_fused_target_kernels_equal_the_torch_formulation(kwargs):
         assert torch.equal(a[k], b[k]), k
     if kwargs.get("ret_box_labels"):
         assert torch.equal(a["point_box_labels"], b["point_box_labels"])
+    # the single-launch form (both box queries, assignment and box-coder targets in one kernel): same integers, same boxes,
+    # box-coder targets to f32 rounding of the logs / divisions
+    c = head.assign_stack_targets_IASSD(pts, gt8, None, extra_width=[0.5, 0.5, 0.5], **kwargs)
+    for k in ("point_cls_labels", "box_idxs_labels", "gt_box_of_points"):
+        assert torch.equal(c[k], b[k]), k
+    if kwargs.get("ret_box_labels"):
+        assert torch.allclose(c["point_box_labels"], b["point_box_labels"], rtol=1e-6, atol=1e-6)
+        assert torch.equal(c["point_box_labels"][:, 6], b["point_box_labels"][:, 6])          # heading bins
     # soft masks
     head.forward_ret_dict = {"sa_ins_labels": [a["point_cls_labels"]], "sa_gt_box_of_points": [a["gt_box_of_points"]],
                              "sa_xyz_coords": [bd["encoder_coords"][1]]}
