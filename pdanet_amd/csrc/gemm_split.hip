@@ -23,33 +23,14 @@
 //       streams them through a double-buffered LDS tile (2 k-steps = 24 KB per buffer, one barrier per 48 MFMAs),
 //       global -> registers -> LDS, the loads of the next tile in flight under the MFMAs of the current one.
 #include "pda_common.h"
+#include "split_bf16.h"
 
 #include <stdlib.h>
 
 namespace pda {
 
-typedef float gs_f32x16 __attribute__((ext_vector_type(16)));
-typedef __bf16 gs_bf16x8 __attribute__((ext_vector_type(8)));
-
 constexpr int GS_MAX_N = 2048;                   // widest output (bias staged in LDS)
 constexpr int GS_KSTEP = 12 * 64;                // uint4 per k-step of a 128-output chunk (4 row blocks x 3 planes x 64 lanes)
-
-// One 16-byte LDS-DMA per lane: global (per-lane address) -> LDS (wave-uniform byte address in M0 + lane * 16), no VGPR
-// in between.  Written as asm so that hipcc does not know about the pending LDS write: with the builtin it puts
-// s_waitcnt vmcnt(0) in front of every ds_read of the ring, which serialises the DMA of tile t + 2 with the MFMAs of
-// tile t.  The waits are the counted ones in the kernel.
-__device__ __forceinline__ void glds16(const uint4* g, uint32_t lds_wave_base) {
-    uint32_t keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(g), "s"(lds_wave_base) : "memory");
-}
-
-__device__ __forceinline__ void split2(float x0, float x1, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = f32x2_to_bf16x2(x0, x1);
-    const float r0 = x0 - __uint_as_float(h << 16), r1 = x1 - __uint_as_float(h & 0xffff0000u);
-    m = f32x2_to_bf16x2(r0, r1);
-    l = f32x2_to_bf16x2(r0 - __uint_as_float(m << 16), r1 - __uint_as_float(m & 0xffff0000u));
-}
 
 // W (rows, cols) row-major (trans: the source holds W^T, (cols, rows) row-major) -> fragment-ordered planes.
 __global__ void split_pack_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf, int rows, int cols, int KS,

@@ -13,6 +13,9 @@
 // (deterministic).  Workgroups that share a slice of T are placed on the same XCD so that the second
 // reader of a G / X chunk hits that XCD's L2.
 #include "pda_common.h"
+#include "split_bf16.h"
+
+#include <stdlib.h>
 
 namespace pda {
 
@@ -180,6 +183,181 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
     }
 }
 
+// ---- wide layers over many tokens: the same reduction on the bf16 matrix cores (split-bf16, csrc/split_bf16.h) ------
+// wgrad_kernel is bound by v_mfma_f32_32x32x2_f32 (157 TFLOP/s: it reaches 100-127).  Here both operands are split into
+// three bf16 terms and six of the nine products are kept (gemm_split.hip has the error analysis): 2.67x the f32 matrix
+// rate at f32 accuracy.  A workgroup (8 waves, 4 x 2) owns a 256 x 256 tile of dW and one slice of T and works in steps
+// of 16 tokens.  The MFMA operands want 8 consecutive tokens of one column per lane, the matrices are [token][column]:
+//   * producer role: wave w owns columns 32 w .. 32 w + 31 of both operands.  Lane (c, h) loads the eight values
+//     [8 h + j][c] of a step straight into registers (128 contiguous bytes per half-wave and row), two steps ahead,
+//     splits them (each value is split ONCE per workgroup) and writes the three planes as ready-made MFMA fragments
+//     [operand][32-column block][plane][lane] x 16 bytes into one of two LDS buffers -- no transposing store, no bank
+//     conflict on either side;
+//   * consumer role: wave (wn, wm) computes 64 (n) x 128 (m): 18 ds_read_b128 for 48 MFMAs per step.
+// The split and the plane stores of step s + 1 sit under the MFMAs of step s; one barrier per step.
+#ifndef WSP_ABL
+#define WSP_ABL 0
+#endif
+constexpr int WSP_TILE_U4 = 2 * 8 * 3 * 64;      // uint4 per plane buffer: 48 KB
+
+__global__ __launch_bounds__(512, 1)
+void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ part_w,
+                        float* __restrict__ part_b, int64_t T, int M, int N, int tiles_m, int tiles_n, int S, int64_t KS,
+                        int nblocks) {
+    extern __shared__ uint4 wsp_planes[];        // 2 * WSP_TILE_U4
+    const int per_xcd = (nblocks + 7) / 8;       // workgroups of one slice on one XCD (they read the same rows)
+    const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (logical >= nblocks) return;
+    const int tiles = tiles_m * tiles_n;
+    const int tile = logical % tiles, s = logical / tiles;
+    const int n0 = (tile / tiles_m) * 256, m0 = (tile % tiles_m) * 256;
+    const int64_t t_begin = (int64_t)s * KS, t_end = (t_begin + KS < T) ? t_begin + KS : T;
+    const int len = (int)(t_end - t_begin), ksteps = (len + 15) >> 4;
+
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 31, h = lane >> 5;
+    const int wn = w >> 1, wm = w & 1;
+    // producer addresses: a buffer resource over the wave's 32 columns of the slice (wave-uniform), one per-lane offset
+    // and the row as the instruction's scalar offset.  The resource ends behind the last row of the slice: rows beyond
+    // it (the ragged last step, the two look-ahead steps) read as 0.0 by the hardware's range check.
+    const uint32_t span_g = (uint32_t)((((int64_t)len - 1) * N + 32) * 4), span_x = (uint32_t)((((int64_t)len - 1) * M + 32) * 4);
+    const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + t_begin * N + n0 + 32 * w), 0, span_g, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(X + t_begin * M + m0 + 32 * w), 0, span_x, 0x00020000);
+    const int vg = (8 * h * N + c) * 4, vx = (8 * h * M + c) * 4;
+    auto load = [&](int st, float (&g)[8], float (&x)[8]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            g[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vg, (16 * st + j) * N * 4, 0));
+            x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx, (16 * st + j) * M * 4, 0));
+        }
+    };
+    float bsum = 0.f;
+    const bool do_bias = part_b && m0 == 0;
+    gs_f32x16 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    const int aoff = (2 * wn) * 192 + lane, boff = (8 + 4 * wm) * 192 + lane;
+    uint4* const my_planes = wsp_planes + w * 192 + lane;          // + b * WSP_TILE_U4 [+ 8 * 192 for X] + plane * 64
+
+    // One step.  ga / xa hold the raw values of step st + 1 (split here), gb / xb receive those of step st + 2.  The
+    // order below is the issue order (sched_barrier fences): the split's VALU work in eight pieces, each behind three
+    // MFMAs that are independent of it.
+    auto step = [&](int st, const float (&ga)[8], const float (&xa)[8], float (&gb)[8], float (&xb)[8]) {
+#if WSP_ABL != 4
+        __syncthreads();                   // planes of step st are complete; everyone is done with step st - 1
+#endif
+#if WSP_ABL != 3
+        load(st + 2, gb, xb);              // in flight for the whole of this step and most of the next
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        const uint4* buf = wsp_planes + (st & 1) * WSP_TILE_U4;
+        uint4* out = my_planes + ((st + 1) & 1) * WSP_TILE_U4;
+        gs_bf16x8 A[2][3], B[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) A[i][pl] = __builtin_bit_cast(gs_bf16x8, buf[aoff + i * 192 + pl * 64]);
+        auto read_b = [&](int jt) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) B[jt & 1][pl] = __builtin_bit_cast(gs_bf16x8, buf[boff + jt * 192 + pl * 64]);
+        };
+        // product p of the six, smallest terms first: (A plane, B plane)
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+        auto mfma3 = [&](int jt, int k) {                         // MFMAs 3k .. 3k + 2 of the 12 of column block jt
+#pragma unroll
+            for (int e = 3 * k; e < 3 * k + 3; ++e) {
+                const int i = e & 1, p = e >> 1;                   // alternate the two accumulators
+#if WSP_ABL == 2
+                if (e != 0) continue;
+#endif
+                acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA[p]], B[jt & 1][PB[p]], acc[i][jt], 0, 0, 0);
+            }
+        };
+        read_b(0);
+        read_b(1);
+        uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mfma3(0, q);
+            __builtin_amdgcn_sched_barrier(0);
+#if WSP_ABL == 1
+            ph[q] = __float_as_uint(ga[2 * q]); pm[q] = __float_as_uint(ga[2 * q + 1]); pl[q] = ph[q] ^ pm[q];
+#else
+            split2(ga[2 * q], ga[2 * q + 1], ph[q], pm[q], pl[q]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        out[64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        out[128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        bsum += ((ga[0] + ga[1]) + (ga[2] + ga[3])) + ((ga[4] + ga[5]) + (ga[6] + ga[7]));      // used by the m0 == 0 workgroups
+        read_b(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mfma3(1, q);
+            __builtin_amdgcn_sched_barrier(0);
+#if WSP_ABL == 1
+            ph[q] = __float_as_uint(xa[2 * q]); pm[q] = __float_as_uint(xa[2 * q + 1]); pl[q] = ph[q] ^ pm[q];
+#else
+            split2(xa[2 * q], xa[2 * q + 1], ph[q], pm[q], pl[q]);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        out[8 * 192] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        out[8 * 192 + 64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        out[8 * 192 + 128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        read_b(3);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfma3(2, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfma3(3, q);
+    };
+    auto split_store = [&](const float (&g)[8], const float (&x)[8], int b) {     // the first step's planes
+        uint4* out = my_planes + b * WSP_TILE_U4;
+        uint32_t ph[4], pm[4], pl[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2(g[2 * q], g[2 * q + 1], ph[q], pm[q], pl[q]);
+        out[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        out[64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        out[128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2(x[2 * q], x[2 * q + 1], ph[q], pm[q], pl[q]);
+        out[8 * 192] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        out[8 * 192 + 64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        out[8 * 192 + 128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        bsum += ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
+    };
+    float g1[8], x1[8], g2[8], x2[8];
+    load(0, g1, x1);
+    split_store(g1, x1, 0);
+    load(1, g1, x1);
+    for (int st = 0; st < ksteps; st += 2) {       // in pairs (the register sets swap roles); a step behind the last adds zeros
+        step(st, g1, x1, g2, x2);
+        step(st + 1, g2, x2, g1, x1);
+    }
+    // D[row n][col m]: lane (c = m, h), register r -> n = (r & 3) + 8 * (r >> 2) + 4 * h
+    float* pw = part_w + (size_t)s * N * M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int m = m0 + 128 * wm + 32 * jt + c;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + 64 * wn + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * h;
+                pw[(size_t)n * M + m] = acc[i][jt][r];
+            }
+        }
+    if (do_bias) {
+        const float v = bsum + __shfl_xor(bsum, 32);
+        if (h == 0) part_b[(size_t)s * N + n0 + 32 * w + c] = v;
+    }
+}
+
 // second stage: out[e] = sum_s part[s][e], fixed order.  Block = 64 elements x 16 slices of S (independent loads
 // in groups of 8: a thread walking all S partials alone would serialise S load latencies).
 __device__ __forceinline__ float sum_slices(const float* __restrict__ part, int S, int64_t stride, int64_t e, bool live, int slice,
@@ -325,6 +503,27 @@ static void wgrad_plan(int64_t T, int M, int N, int& tiles_m, int& tiles_n, int&
     S = (int)divup64(T, KS);
 }
 
+// The split form: both widths whole 256-column tiles and enough work that its 256 KB of partials per workgroup
+// (64 MB per call, written and summed once) stay a small part of the call.  PDA_WGRAD_SPLIT=0 keeps the f32-MFMA form,
+// =2 takes the split form whenever the shape allows.
+static bool wgrad_use_split(int64_t T, int M, int N) {
+    static const int mode = [] { const char* e = getenv("PDA_WGRAD_SPLIT"); return e ? atoi(e) : 1; }();   // 2: whenever the shape allows
+    if (mode == 0 || (M & 255) || (N & 255) || T < 4096) return false;
+    return mode == 2 || (double)T * M * N >= 2.0e9;      // measured cross-over: 32768 x 256 x 256 wins, 12979 x 256 x 256 loses
+}
+static void wgrad_split_plan(int64_t T, int M, int N, int& tiles_m, int& tiles_n, int& S, int64_t& KS) {
+    tiles_m = M / 256; tiles_n = N / 256;
+    const int tiles = tiles_m * tiles_n;
+    int64_t s = 256 / tiles;                       // one workgroup per CU
+    const int64_t max_s = T / 256 > 0 ? T / 256 : 1;
+    if (s > max_s) s = max_s;
+    const int64_t min_s = divup64(T * (M > N ? M : N) * 4, (int64_t)1 << 31);     // a slice is addressed with 32-bit offsets
+    if (s < min_s) s = min_s;
+    if (s < 1) s = 1;
+    KS = divup64(divup64(T, s), 16) * 16;
+    S = (int)divup64(T, KS);
+}
+
 }  // namespace pda
 
 PDA_API int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_features) {
@@ -332,6 +531,7 @@ PDA_API int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, 
     int tm, tn, S;
     int64_t KS;
     if (pda::wgrad_is_skinny(in_features, out_features)) pda::wgrad_skinny_plan(tokens, S, KS);
+    else if (pda::wgrad_use_split(tokens, in_features, out_features)) pda::wgrad_split_plan(tokens, in_features, out_features, tm, tn, S, KS);
     else pda::wgrad_plan(tokens, in_features, out_features, tm, tn, S, KS);
     return (int64_t)S * ((int64_t)in_features * out_features + out_features) * (int64_t)sizeof(float);
 }
@@ -360,6 +560,21 @@ PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_
         const int64_t nm = (int64_t)N * M;
         hipLaunchKernelGGL(pda::wgrad_reduce_kernel, dim3((unsigned)pda::divup64(nm, 64)), dim3(1024), 0, st, pw, pb, grad_weight,
                            grad_bias, S, nm, N);
+        return pda::check_launch("pda_linear_wgrad");
+    }
+    if (pda::wgrad_use_split(tokens, M, N)) {
+        pda::wgrad_split_plan(tokens, M, N, tm, tn, S, KS);
+        const int nblocks = S * tm * tn;
+        float* part_w = (float*)scratch;
+        float* part_b = part_w + (size_t)S * N * M;
+        static const bool ok = hipFuncSetAttribute((const void*)pda::wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                   2 * pda::WSP_TILE_U4 * 16) == hipSuccess;
+        PDA_REQUIRE(ok, "pda_linear_wgrad: %d bytes of dynamic LDS refused", 2 * pda::WSP_TILE_U4 * 16);
+        hipLaunchKernelGGL(pda::wgrad_split_kernel, dim3(pda::divup(nblocks, 8) * 8), dim3(512), 2 * pda::WSP_TILE_U4 * 16, st,
+                           x, grad_out, part_w, grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks);
+        const int64_t nm = (int64_t)N * M;
+        hipLaunchKernelGGL(pda::wgrad_reduce_kernel, dim3((unsigned)pda::divup64(nm, 64)), dim3(1024), 0, st, part_w, part_b,
+                           grad_weight, grad_bias, S, nm, N);
         return pda::check_launch("pda_linear_wgrad");
     }
     pda::wgrad_plan(tokens, M, N, tm, tn, S, KS);

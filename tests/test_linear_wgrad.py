@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
                                                      (50000, 64, 4, True), (300, 32, 64, True),
                                                      # wgrad_skinny_kernel: the layer-0 and position-MLP shapes, ragged token counts
                                                      (1048576, 4, 32, True), (1048576, 32, 64, True), (524288, 16, 16, False),
-                                                     (32307, 12, 32, True), (64394, 64, 64, True), (8193, 36, 60, True)])
+                                                     (32307, 12, 32, True), (64394, 64, 64, True), (8193, 36, 60, True),
+                                                     # wgrad_split_kernel (both widths whole 256-column tiles): ragged token counts, 1-12 tiles
+                                                     (62517, 512, 256, True), (70001, 256, 768, False), (131072, 256, 256, True),
+                                                     (48365, 512, 1536, True), (100003, 512, 512, True)])
 def test_gradients(tokens, n_in, n_out, bias):
     from pdanet_amd import pointnet2_utils as pu
     torch.manual_seed(tokens % 1000 + n_in)
