@@ -218,15 +218,24 @@ class KernelTimers:
         flops = 2.0 * t * ni * no
         total = sum(sum(v) for v in by.values())
         steps = max(1, len(self.fps_events))          # one D-FPS launch per step
-        key = "pda::wgrad_kernel dW(%dx%d) over %d tokens" % (no, ni, t)
-        util = pmc_record("mfma_util", "pda::wgrad_kernel", ["wgrad.hip"], prefix=True, by="launches")
-        return {"kernel": key[5:], "bound": "mfma", "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
-                "achieved": flops / avg / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": flops / avg / 1e12 / F32_MFMA_PEAK_TF, "traffic": pmc_traffic(key, ["wgrad.hip"]),
+        from pdanet_amd import _lib
+        split = int(_lib.load().pda_linear_wgrad_form(t, ni, no)) == 2
+        kern = "wgrad_split_kernel" if split else "wgrad_kernel"
+        key = "pda::linear_wgrad dW(%dx%d) over %d tokens" % (no, ni, t)
+        util = pmc_record("mfma_util", "pda::" + kern, ["wgrad.hip"], prefix=True, by="launches")
+        ach = flops / avg / 1e12
+        note = ("three-term bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per f32 product block (f32 accuracy); peak = "
+                "the f32 MFMA peak the same contraction had before (a fraction above 1 means faster than any f32-input MFMA kernel "
+                "can be), the bf16 pipe's nominal ceiling for this form is 2500/6 = 416.7 TFLOP/s f32-equivalent "
+                "(frac_of_split_ceiling); on random data the chip holds ~1.8 GHz under this load (mfma_util.json clock_ghz)"
+                if split else "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)")
+        return {"kernel": "%s dW(%dx%d) over %d tokens" % (kern, no, ni, t), "bound": "mfma",
+                "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
+                "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF,
+                "frac_of_split_ceiling": (ach / (2500.0 / 6.0)) if split else None, "traffic": pmc_traffic(key, ["wgrad.hip"]),
                 "avg_launch_ms": avg * 1e3,
-                "note": "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate); event-timed launch = split-K kernel + "
-                        "fixed-order second stage; all %d wgrad launches of a step: %.2f ms" % (
-                            sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
+                "note": note + "; event-timed launch = split-K kernel + fixed-order second stage; all %d wgrad launches of a "
+                        "step: %.2f ms" % (sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
 
 
 class SamplingGroupingWorkload(KernelTimers):

@@ -95,8 +95,11 @@ int pda_layer_norm_bwd_mixed(const float *x, const float *grad_y, const void *gr
  * grad_out (tokens, out), both row-major -> grad_weight (out, in) = grad_out^T x (the layout of
  * nn.Linear.weight / Conv.weight.flatten(1)) and, when grad_bias != NULL, grad_bias (out) = column sums
  * of grad_out.  Split over the token axis with a fixed-order second stage (deterministic).
- * in, out: multiples of 4.  scratch: pda_linear_wgrad_scratch_bytes(tokens, in, out) bytes. */
+ * in, out: multiples of 4.  scratch: pda_linear_wgrad_scratch_bytes(tokens, in, out) bytes.
+ * pda_linear_wgrad_form: which kernel a call of this shape runs -- 0 the f32-MFMA split-K form, 1 the streaming form of
+ * narrow layers (in, out <= 64), 2 the split-bf16 form (in, out multiples of 256, tokens * in * out >= 2e9). */
 int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_features);
+int pda_linear_wgrad_form(int64_t tokens, int in_features, int out_features);
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
 /* Dense-bf16 mode: the bias gradient alone, column sums of the bf16 gradient g (rows, cols) -> out (cols) fp32 (fixed

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -74,6 +74,7 @@ SIGNATURES = {
     "pda_layer_norm_fwd_mixed": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _vp],
     "pda_layer_norm_bwd_mixed": [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
+    "pda_linear_wgrad_form": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_colsum_scratch_bytes": [_i],
     "pda_colsum_bf16": [_vp, _vp, _vp, ctypes.c_int64, _i, _vp],

@@ -228,6 +228,7 @@ struct GemmSplitParams {
 
 constexpr int GT_XCHUNKS = 128 * 4;                  // uint4 per X tile (128 rows x 64 bytes)
 constexpr int GT_SLOT = GT_XCHUNKS + GS_KSTEP;       // + 768 uint4 of W planes = 20 KB per slot
+constexpr int GW_TILE_U4 = (8 + 8) * 192;            // gemm_split_wide_kernel: uint4 per plane buffer (48 KB)
 
 __global__ __launch_bounds__(256, 2)
 void gemm_split_kernel(const GemmSplitParams p) {
@@ -346,50 +347,56 @@ void gemm_split_kernel(const GemmSplitParams p) {
 }
 
 // gemm_split_wide_kernel: 8 waves (4 x 2) per workgroup = 256 tokens x 256 outputs, a wave computes 64 x 128 (2 x 4 MFMA
-// tiles, 128 accumulator registers).  Against the 128 x 128 form this halves what sits between the MFMAs: per K step a wave
-// splits two X fragments (88 VALU) and reads 16 fragments for 48 MFMAs instead of 24, and there is one barrier per 48.
-// (Measured on the 128 x 128 form: without the split AND without the stores it still stops at 200 TFLOP/s f32-equivalent --
-// the loop's own LDS reads, DMA issue and barrier are the limit there; a five-slot ring with the DMA four steps ahead changed
-// nothing, so DMA latency is not.)  One workgroup per CU (3 slots x 40 KB), two waves per SIMD.
-constexpr int GW_XCHUNKS = 256 * 4;                  // uint4 per X tile (256 rows x 64 bytes)
-constexpr int GW_SLOT = GW_XCHUNKS + 2 * GS_KSTEP;   // + two 128-output chunks of W planes = 40 KB
-constexpr int GW_SLOTS = 3;
+// tiles, 128 accumulator registers), with the loop structure of wgrad_split_kernel (csrc/wgrad.hip):
+//   * producer role: wave w owns tokens 32 w .. 32 w + 31 of the tile: lane (r, h) loads X[token r][16 s + 8 h .. + 7]
+//     (two 16-byte loads, a step ahead in registers), splits them -- every X value ONCE per workgroup instead of once
+//     per wave that uses it -- and stores the three planes as ready MFMA fragments; the packed W planes of the step
+//     (24 KB, fragment-ordered by split_pack_kernel) go global -> registers -> LDS, three 16-byte pieces per lane;
+//   * consumer role: wave (wt, wo) computes 64 tokens x 128 outputs: 18 ds_read_b128 for 48 MFMAs per K step.
+// Two plane buffers of 48 KB, one barrier per K step; the last quarter of a step's MFMAs is issued behind the NEXT step's
+// barrier (over the latency of its first fragment reads), the split in four pieces behind three MFMAs each, stores and
+// loads one per three MFMAs.  K a multiple of 32: the steps come in pairs (the register sets swap roles).
+// Measured against the form this replaces (both operands through a 3-slot LDS-DMA ring, X split by every wave that reads
+// it: bf16 pipe 52 % busy; an LDS-DMA piece costs 100-185 issue cycles inside a busy phase, MI355X_MICROARCH.md): 3-9 %
+// less time on the step's shapes.  Four waves per workgroup and two workgroups per CU (128 x 256 tiles) measured 3-8 %
+// slower than this form: the output stores are not what holds it back.
+typedef uint32_t gp_u32x4 __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(512, 1)
 void gemm_split_wide_kernel(const GemmSplitParams p) {
-    extern __shared__ uint4 ring[];                  // GW_SLOTS * GW_SLOT
+    constexpr int TW = 4;                           // token-waves (x 2 output-waves)
+    constexpr int XF = 2 * TW;                      // X fragments (32 tokens each) per tile
+    constexpr int NP = 24 / (2 * TW);               // W pieces (1 KB) per wave and step
+    constexpr int TILE_U4 = GW_TILE_U4;             // uint4 per plane buffer: X fragments, then W pieces 0..23
+    extern __shared__ uint4 gp_planes[];            // 2 * TILE_U4
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, r = lane & 31;
-    const int wt = w & 3, wo = w >> 2;
+    const int wt = w % TW, wo = w / TW;
     const int wide_chunks = (p.chunks + 1) >> 1;
     const int ncb = (int)(blockIdx.x % (unsigned)wide_chunks);
-    const int64_t tok0 = (int64_t)(blockIdx.x / (unsigned)wide_chunks) * 256;
-    const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring;
-    const float* xsrc[2];
+    const int64_t tok0 = (int64_t)(blockIdx.x / (unsigned)wide_chunks) * (64 * TW);
+    // producer sources
+    const int64_t ptok = tok0 + 32 * w + r < p.tokens ? tok0 + 32 * w + r : p.tokens - 1;
+    const float* xsrc = p.x + ptok * p.k + 8 * h;
+    const uint4* wsrc[NP];
 #pragma unroll
-    for (int e = 0; e < 2; ++e) {
-        const int pch = 64 * (2 * w + e) + lane, row = pch >> 2, cl = pch & 3, c = cl ^ ((row >> 2) & 3);
-        const int64_t tok = tok0 + row < p.tokens ? tok0 + row : p.tokens - 1;
-        xsrc[e] = p.x + tok * p.k + 4 * c;
-    }
-    // W pieces 3w .. 3w + 2 of the 24 (12 per 128-output chunk); an odd chunk count repeats the last chunk (its columns are
-    // beyond n_out and never stored)
-    const uint4* wsrc[3];
-#pragma unroll
-    for (int e = 0; e < 3; ++e) {
-        const int piece = 3 * w + e, half = piece / 12, j = piece - 12 * half;
+    for (int e = 0; e < NP; ++e) {
+        const int piece = NP * w + e, half = piece / 12, j = piece - 12 * half;
         int chunk = 2 * ncb + half;
-        if (chunk >= p.chunks) chunk = p.chunks - 1;
+        if (chunk >= p.chunks) chunk = p.chunks - 1;      // an odd chunk count repeats the last chunk (never stored)
         wsrc[e] = p.wf + (size_t)chunk * p.ksteps * GS_KSTEP + 64 * j + lane;
     }
-    auto issue = [&](int s, int slot) {
-        const int ss = s < p.ksteps ? s : p.ksteps - 1;
-        const uint32_t base = ring_base + slot * (GW_SLOT * 16);
+    auto wld = [&](int e, int ss) { return *reinterpret_cast<const gp_u32x4*>(wsrc[e] + (size_t)ss * GS_KSTEP); };
+    auto wst = [&](uint4* dst, const gp_u32x4& v) { *reinterpret_cast<gp_u32x4*>(dst) = v; };
+    auto load = [&](int st, float4 (&x)[2], gp_u32x4 (&wv)[NP]) {
+        const int ss = st < p.ksteps ? st : p.ksteps - 1;              // behind the last step: the last step again, never used
+        x[0] = *reinterpret_cast<const float4*>(xsrc + 16 * ss);
+        x[1] = *reinterpret_cast<const float4*>(xsrc + 16 * ss + 4);
 #pragma unroll
-        for (int e = 0; e < 2; ++e) glds16(reinterpret_cast<const uint4*>(xsrc[e] + 16 * ss), base + (2 * w + e) * 1024);
-#pragma unroll
-        for (int e = 0; e < 3; ++e) glds16(wsrc[e] + (size_t)ss * GS_KSTEP, base + GW_XCHUNKS * 16 + (3 * w + e) * 1024);
+        for (int e = 0; e < NP; ++e) wv[e] = wld(e, ss);
     };
+    uint4* const my_x = gp_planes + w * 192 + lane;                     // + buffer * TILE_U4 + plane * 64
+    uint4* const my_w = gp_planes + XF * 192 + (NP * w) * 64 + lane;    // + buffer * TILE_U4 + e * 64
     gs_f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -397,56 +404,107 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
         for (int b = 0; b < 4; ++b)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    int xoff[2][2];
+    const int aoff = (2 * wt) * 192 + lane, boff = (XF + 4 * wo) * 192 + lane;
+    gs_bf16x8 Bf[2][3];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // the six products, smallest terms first
+
+    // One step (issue order = source order, sched_barrier fences).  xa / wa: the raw values of step st + 1 (split and
+    // stored here), xb / wb receive those of step st + 2.  Ap: the previous step's token fragments, An: this step's.
+    auto step = [&](int st, const float4 (&xa)[2], const gp_u32x4 (&wa)[NP], float4 (&xb)[2], gp_u32x4 (&wb)[NP],
+                    const gs_bf16x8 (&Ap)[2][3], gs_bf16x8 (&An)[2][3]) {
+        __syncthreads();                   // planes of step st are complete; everyone is done with step st - 1
+        const uint4* buf = gp_planes + (st & 1) * TILE_U4;
+        const int ob = ((st + 1) & 1) * TILE_U4;
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-        const int row = wt * 64 + tt * 32 + r;
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) xoff[tt][e] = row * 4 + ((2 * h + e) ^ ((row >> 2) & 3));
-    }
-    const int woff = GW_XCHUNKS + wo * GS_KSTEP + lane;       // my 128-output chunk: [row block][plane][lane]
-    issue(0, 0);
-    issue(1, 1);
-    int slot = 0;
-    for (int s = 0; s < p.ksteps; ++s, slot = slot == GW_SLOTS - 1 ? 0 : slot + 1) {
-        asm volatile("s_waitcnt vmcnt(5)" ::: "memory");      // my part of tile s has landed (tile s + 1 may be in flight)
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        issue(s + 2, slot == 0 ? GW_SLOTS - 1 : slot - 1);
-        const uint4* buf = ring + slot * GW_SLOT;
-        uint4 wfr[4][3];
+            for (int pl = 0; pl < 3; ++pl) An[i][pl] = __builtin_bit_cast(gs_bf16x8, buf[aoff + i * 192 + pl * 64]);
+        auto read_b = [&](int jt) {
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot)
+            for (int pl = 0; pl < 3; ++pl) Bf[jt & 1][pl] = __builtin_bit_cast(gs_bf16x8, buf[boff + jt * 192 + pl * 64]);
+        };
+        auto mfma3 = [&](const gs_bf16x8 (&A)[2][3], int jt, int k) {     // MFMAs 3k .. 3k + 2 of the 12 of output block jt
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) wfr[ot][pl] = buf[woff + (ot * 3 + pl) * 64];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const uint4 a = buf[xoff[tt][0]], b = buf[xoff[tt][1]];
-            uint32_t bh[4], bm[4], bl[4];
-            split2(__uint_as_float(a.x), __uint_as_float(a.y), bh[0], bm[0], bl[0]);
-            split2(__uint_as_float(a.z), __uint_as_float(a.w), bh[1], bm[1], bl[1]);
-            split2(__uint_as_float(b.x), __uint_as_float(b.y), bh[2], bm[2], bl[2]);
-            split2(__uint_as_float(b.z), __uint_as_float(b.w), bh[3], bm[3], bl[3]);
-            const gs_bf16x8 Xh = __builtin_bit_cast(gs_bf16x8, make_uint4(bh[0], bh[1], bh[2], bh[3]));
-            const gs_bf16x8 Xm = __builtin_bit_cast(gs_bf16x8, make_uint4(bm[0], bm[1], bm[2], bm[3]));
-            const gs_bf16x8 Xl = __builtin_bit_cast(gs_bf16x8, make_uint4(bl[0], bl[1], bl[2], bl[3]));
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot) {
-                const gs_bf16x8 Wh = __builtin_bit_cast(gs_bf16x8, wfr[ot][0]);
-                const gs_bf16x8 Wm = __builtin_bit_cast(gs_bf16x8, wfr[ot][1]);
-                const gs_bf16x8 Wl = __builtin_bit_cast(gs_bf16x8, wfr[ot][2]);
-                gs_f32x16 c = acc[tt][ot];
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xl, Wh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wl, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xm, Wh, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wm, c, 0, 0, 0);
-                c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wh, c, 0, 0, 0);
-                acc[tt][ot] = c;
+            for (int e = 3 * k; e < 3 * k + 3; ++e) {
+                const int i = e & 1, pr = e >> 1;
+                acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA[pr]], Bf[jt & 1][PB[pr]], acc[i][jt], 0, 0, 0);
             }
+        };
+        read_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfma3(Ap, 3, q);                       // the previous step's output block 3
+        __builtin_amdgcn_sched_barrier(0);
+        read_b(1);
+        uint32_t ph[4], pm[4], pl[4];
+        const float xv[8] = {xa[0].x, xa[0].y, xa[0].z, xa[0].w, xa[1].x, xa[1].y, xa[1].z, xa[1].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            mfma3(An, 0, q);
+            __builtin_amdgcn_sched_barrier(0);
+            split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
+            __builtin_amdgcn_sched_barrier(0);
         }
+        my_x[ob] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        my_x[ob + 64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        my_x[ob + 128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+        read_b(2);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                      // the W pieces of step st + 1: registers -> LDS
+            mfma3(An, 1, q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < NP; ++e)
+                if (e * 4 / NP == q) wst(my_w + ob + 64 * e, wa[e]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_b(3);                          // stays in Bf[1] for the MFMAs behind the next barrier
+        const int ss = st + 2 < p.ksteps ? st + 2 : p.ksteps - 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                                      // the loads of step st + 2
+            mfma3(An, 2, q);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q == 0) {
+                xb[0] = *reinterpret_cast<const float4*>(xsrc + 16 * ss);
+                xb[1] = *reinterpret_cast<const float4*>(xsrc + 16 * ss + 4);
+            }
+#pragma unroll
+            for (int e = 0; e < NP; ++e)
+                if ((e + 1) * 4 / (NP + 1) == q) wb[e] = wld(e, ss);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    float4 x1[2], x2[2];
+    gp_u32x4 w1[NP], w2[NP];
+    gs_bf16x8 A0[2][3], A1[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            A0[i][pl] = __builtin_bit_cast(gs_bf16x8, make_uint4(0u, 0u, 0u, 0u));      // "the step before the first": zeros
+            Bf[1][pl] = A0[i][pl];
+        }
+    load(0, x1, w1);
+    {                                                                   // the first step's planes
+        uint32_t ph[4], pm[4], pl[4];
+        const float xv[8] = {x1[0].x, x1[0].y, x1[0].z, x1[0].w, x1[1].x, x1[1].y, x1[1].z, x1[1].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
+        my_x[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+        my_x[64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
+        my_x[128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+#pragma unroll
+        for (int e = 0; e < NP; ++e) wst(my_w + 64 * e, w1[e]);
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    load(1, x1, w1);
+    for (int st = 0; st < p.ksteps; st += 2) {
+        step(st, x1, w1, x2, w2, A0, A1);
+        step(st + 1, x2, w2, x1, w1, A1, A0);
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e)                   // output block 3 of the last step
+        acc[e & 1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[e & 1][PA[e >> 1]], Bf[1][PB[e >> 1]], acc[e & 1][3], 0, 0, 0);
+    // rows of a 32 x 32 tile: token (i & 3) + 8 (i >> 2) + 4 h; column: output (2 ncb + wo) * 128 + ot * 32 + r
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
         const int col = (2 * ncb + wo) * 128 + ot * 32 + r;
@@ -463,9 +521,6 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
                     float v = acc[tt][ot][i] + bias;
                     if (p.accum) v += *dst;
                     if (p.relu) v = fmaxf(v, 0.f);
-#ifdef GS_NOSTORE
-                    if (v == 12345.678f)
-#endif
                     *dst = v;
                 }
             }
@@ -546,9 +601,9 @@ PDA_API int pda_gemm_split(const float* x, const void* wf, const float* bias, fl
     const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
     if (force == 256 || (force != 128 && wide_blocks >= 200 && (p.chunks % 2 == 0 || p.chunks >= 5))) {
         static const bool ok = hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   pda::GW_SLOTS * pda::GW_SLOT * 16) == hipSuccess;
+                                                   2 * pda::GW_TILE_U4 * 16) == hipSuccess;
         if (ok) {
-            hipLaunchKernelGGL(pda::gemm_split_wide_kernel, dim3((unsigned)wide_blocks), dim3(512), pda::GW_SLOTS * pda::GW_SLOT * 16,
+            hipLaunchKernelGGL(pda::gemm_split_wide_kernel, dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16,
                                (hipStream_t)stream, p);
             return pda::check_launch("pda_gemm_split");
         }

@@ -195,6 +195,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
 //     conflict on either side;
 //   * consumer role: wave (wn, wm) computes 64 (n) x 128 (m): 18 ds_read_b128 for 48 MFMAs per step.
 // The split and the plane stores of step s + 1 sit under the MFMAs of step s; one barrier per step.
+// Timing experiments only (results are wrong): -DWSP_ABL=1 no split arithmetic, 2 one MFMA in twelve, 3 no loads in the loop,
+// 4 no barrier.  rocprofv3 counters on 131072 x 512 x 512: the bf16 pipe is 69 % busy at a 1.8 GHz clock = 1.3 PFLOP/s of
+// bf16 MFMA work on random data, which is where the chip holds its clock down (MI355X_MICROARCH.md, DVFS give-back):
+// 7 % fewer wave cycles from the deferred quarter came back as a 4 % lower clock.
 #ifndef WSP_ABL
 #define WSP_ABL 0
 #endif
@@ -224,12 +228,13 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
     const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(G + t_begin * N + n0 + 32 * w), 0, span_g, 0x00020000);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(X + t_begin * M + m0 + 32 * w), 0, span_x, 0x00020000);
     const int vg = (8 * h * N + c) * 4, vx = (8 * h * M + c) * 4;
+    auto load1 = [&](int st, int j, float (&g)[8], float (&x)[8]) {
+        g[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vg, (16 * st + j) * N * 4, 0));
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx, (16 * st + j) * M * 4, 0));
+    };
     auto load = [&](int st, float (&g)[8], float (&x)[8]) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            g[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, vg, (16 * st + j) * N * 4, 0));
-            x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vx, (16 * st + j) * M * 4, 0));
-        }
+        for (int j = 0; j < 8; ++j) load1(st, j, g, x);
     };
     float bsum = 0.f;
     const bool do_bias = part_b && m0 == 0;
@@ -244,45 +249,49 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
     uint4* const my_planes = wsp_planes + w * 192 + lane;          // + b * WSP_TILE_U4 [+ 8 * 192 for X] + plane * 64
 
     // One step.  ga / xa hold the raw values of step st + 1 (split here), gb / xb receive those of step st + 2.  The
-    // order below is the issue order (sched_barrier fences): the split's VALU work in eight pieces, each behind three
-    // MFMAs that are independent of it.
-    auto step = [&](int st, const float (&ga)[8], const float (&xa)[8], float (&gb)[8], float (&xb)[8]) {
+    // order below is the issue order (sched_barrier fences):
+    //   * the last quarter of the PREVIOUS step's MFMAs (column block 3: fragments An / Bf[1] still in registers) is issued
+    //     behind this step's barrier, over the latency of this step's first fragment reads -- the two waves of a SIMD reach
+    //     the barrier together, so nothing else could keep the matrix pipe busy there;
+    //   * the split's VALU work in eight pieces, each behind three MFMAs that are independent of it;
+    //   * the sixteen loads two per three MFMAs (all sixteen at once held up both waves of a SIMD).
+    gs_bf16x8 Bf[2][3];
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};     // the six products, smallest terms first
+    auto step = [&](int st, const float (&ga)[8], const float (&xa)[8], float (&gb)[8], float (&xb)[8],
+                    const gs_bf16x8 (&Ap)[2][3], gs_bf16x8 (&An)[2][3]) {
 #if WSP_ABL != 4
         __syncthreads();                   // planes of step st are complete; everyone is done with step st - 1
 #endif
-#if WSP_ABL != 3
-        load(st + 2, gb, xb);              // in flight for the whole of this step and most of the next
-#endif
-        __builtin_amdgcn_sched_barrier(0);
         const uint4* buf = wsp_planes + (st & 1) * WSP_TILE_U4;
         uint4* out = my_planes + ((st + 1) & 1) * WSP_TILE_U4;
-        gs_bf16x8 A[2][3], B[2][3];
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) A[i][pl] = __builtin_bit_cast(gs_bf16x8, buf[aoff + i * 192 + pl * 64]);
+            for (int pl = 0; pl < 3; ++pl) An[i][pl] = __builtin_bit_cast(gs_bf16x8, buf[aoff + i * 192 + pl * 64]);
         auto read_b = [&](int jt) {
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) B[jt & 1][pl] = __builtin_bit_cast(gs_bf16x8, buf[boff + jt * 192 + pl * 64]);
+            for (int pl = 0; pl < 3; ++pl) Bf[jt & 1][pl] = __builtin_bit_cast(gs_bf16x8, buf[boff + jt * 192 + pl * 64]);
         };
-        // product p of the six, smallest terms first: (A plane, B plane)
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
-        auto mfma3 = [&](int jt, int k) {                         // MFMAs 3k .. 3k + 2 of the 12 of column block jt
+        auto mfma3 = [&](const gs_bf16x8 (&A)[2][3], int jt, int k) {     // MFMAs 3k .. 3k + 2 of the 12 of column block jt
 #pragma unroll
             for (int e = 3 * k; e < 3 * k + 3; ++e) {
-                const int i = e & 1, p = e >> 1;                   // alternate the two accumulators
+                const int i = e & 1, p = e >> 1;                           // alternate the two accumulators
 #if WSP_ABL == 2
                 if (e != 0) continue;
 #endif
-                acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA[p]], B[jt & 1][PB[p]], acc[i][jt], 0, 0, 0);
+                acc[i][jt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][PA[p]], Bf[jt & 1][PB[p]], acc[i][jt], 0, 0, 0);
             }
         };
         read_b(0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) mfma3(Ap, 3, q);                       // the previous step's column block 3
+        __builtin_amdgcn_sched_barrier(0);
         read_b(1);
         uint32_t ph[4], pm[4], pl[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            mfma3(0, q);
+            mfma3(An, 0, q);
             __builtin_amdgcn_sched_barrier(0);
 #if WSP_ABL == 1
             ph[q] = __float_as_uint(ga[2 * q]); pm[q] = __float_as_uint(ga[2 * q + 1]); pl[q] = ph[q] ^ pm[q];
@@ -298,7 +307,7 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
         read_b(2);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            mfma3(1, q);
+            mfma3(An, 1, q);
             __builtin_amdgcn_sched_barrier(0);
 #if WSP_ABL == 1
             ph[q] = __float_as_uint(xa[2 * q]); pm[q] = __float_as_uint(xa[2 * q + 1]); pl[q] = ph[q] ^ pm[q];
@@ -310,11 +319,17 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
         out[8 * 192] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         out[8 * 192 + 64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         out[8 * 192 + 128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
-        read_b(3);
+        read_b(3);                          // stays in Bf[1] for the MFMAs behind the next barrier
 #pragma unroll
-        for (int q = 0; q < 4; ++q) mfma3(2, q);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) mfma3(3, q);
+        for (int q = 0; q < 4; ++q) {
+            mfma3(An, 2, q);
+#if WSP_ABL != 3
+            __builtin_amdgcn_sched_barrier(0);
+            load1(st + 2, 2 * q, gb, xb);
+            load1(st + 2, 2 * q + 1, gb, xb);
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
     };
     auto split_store = [&](const float (&g)[8], const float (&x)[8], int b) {     // the first step's planes
         uint4* out = my_planes + b * WSP_TILE_U4;
@@ -332,13 +347,24 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
         bsum += ((g[0] + g[1]) + (g[2] + g[3])) + ((g[4] + g[5]) + (g[6] + g[7]));
     };
     float g1[8], x1[8], g2[8], x2[8];
+    gs_bf16x8 A0[2][3], A1[2][3];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            A0[i][pl] = __builtin_bit_cast(gs_bf16x8, make_uint4(0u, 0u, 0u, 0u));      // "the step before the first": zeros
+            Bf[1][pl] = A0[i][pl];
+        }
     load(0, g1, x1);
     split_store(g1, x1, 0);
     load(1, g1, x1);
     for (int st = 0; st < ksteps; st += 2) {       // in pairs (the register sets swap roles); a step behind the last adds zeros
-        step(st, g1, x1, g2, x2);
-        step(st + 1, g2, x2, g1, x1);
+        step(st, g1, x1, g2, x2, A0, A1);
+        step(st + 1, g2, x2, g1, x1, A1, A0);
     }
+#pragma unroll
+    for (int e = 0; e < 12; ++e)                   // column block 3 of the last step
+        acc[e & 1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[e & 1][PA[e >> 1]], Bf[1][PB[e >> 1]], acc[e & 1][3], 0, 0, 0);
     // D[row n][col m]: lane (c = m, h), register r -> n = (r & 3) + 8 * (r >> 2) + 4 * h
     float* pw = part_w + (size_t)s * N * M;
 #pragma unroll
@@ -534,6 +560,11 @@ PDA_API int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, 
     else if (pda::wgrad_use_split(tokens, in_features, out_features)) pda::wgrad_split_plan(tokens, in_features, out_features, tm, tn, S, KS);
     else pda::wgrad_plan(tokens, in_features, out_features, tm, tn, S, KS);
     return (int64_t)S * ((int64_t)in_features * out_features + out_features) * (int64_t)sizeof(float);
+}
+
+PDA_API int pda_linear_wgrad_form(int64_t tokens, int in_features, int out_features) {
+    if (pda::wgrad_is_skinny(in_features, out_features)) return 1;
+    return pda::wgrad_use_split(tokens, in_features, out_features) ? 2 : 0;
 }
 
 PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_weight, float* grad_bias, void* scratch,

@@ -557,6 +557,14 @@ def _split_gemm_ok(x2d, k):
             and not DENSE_BF16 and not torch.is_autocast_enabled())
 
 
+def _rows_in_registers(tokens, k, n_out):
+    """Which split-bf16 kernel a (tokens, k) x (n_out, k)^T product takes: lin_split_kernel (a wave's rows stay in registers:
+    short K only) is ahead of the 256 x 256 tiles of gemm_split_wide_kernel while those leave a ragged last round of
+    workgroups on the 256 CUs; from ~100k tokens the tiles win (131072 x 256 -> 256: 0.109 against 0.131 ms, -> 512: 0.217
+    against 0.233; 65536 x 256 -> 512: level; 32307 x 256 -> 768: 0.077 against 0.101 for the rows form)."""
+    return k <= 256 and n_out % 128 == 0 and n_out <= 2048 and tokens < 98304
+
+
 def _gemm_nt(x2d, w, bias=None, relu=False):
     """relu?(x2d (T, K) @ w (N, K)^T + bias) in f32."""
     n_out, k = w.shape
@@ -566,7 +574,7 @@ def _gemm_nt(x2d, w, bias=None, relu=False):
         y = torch.empty((T, n_out), dtype=torch.float32, device=x2d.device)
         wf = pointnet2.linear_split_pack(w.detach().contiguous(), n_out, k)
         bias = None if bias is None else bias.detach().contiguous()
-        if k <= 256 and n_out % 128 == 0 and n_out <= 2048:      # short K: the rows-in-registers form is ahead
+        if _rows_in_registers(T, k, n_out):
             pointnet2.linear_split(x2d, wf, bias, y, T, k, n_out, relu=relu)
         else:
             pointnet2.gemm_split(x2d, wf, bias, y, T, k, n_out, relu=relu)
@@ -585,7 +593,7 @@ def _gemm_nn(g2d, w, acc=None):
         T = g2d.shape[0]
         y = acc if acc is not None else torch.empty((T, k_out), dtype=torch.float32, device=g2d.device)
         wf = pointnet2.linear_split_pack(w.detach().contiguous(), k_out, n, transposed_source=True)
-        if acc is None and n <= 256 and k_out % 128 == 0 and k_out <= 2048:
+        if acc is None and _rows_in_registers(T, n, k_out):
             pointnet2.linear_split(g2d, wf, None, y, T, n, k_out)
         else:
             pointnet2.gemm_split(g2d, wf, None, y, T, n, k_out, accumulate=acc is not None)
@@ -867,7 +875,7 @@ def _lin_cols(x2, weight, y, T, k, n_out, transposed):
     """y (T, n_out) = x2 (T, k) W'^T with W' = weight (n_out, k), or weight^T when `transposed` (weight is (k, n_out))."""
     if SPLIT_GEMM:
         wf = pointnet2.linear_split_pack(weight, n_out, k, transposed_source=transposed)
-        if k <= 256:
+        if _rows_in_registers(T, k, n_out):
             _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out))
         else:
             _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.gemm_split(x2, wf, None, y, T, k, n_out))

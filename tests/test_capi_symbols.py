@@ -35,10 +35,22 @@ def test_binding_covers_header():
 
 
 def test_info_entry_points(lib, oracle):
-    assert lib.pda_abi_version() == 16
+    assert lib.pda_abi_version() == 17
     assert lib.pda_fp_contract_mode() == 1
     for n in [1, 2, 3, 7, 8, 100, 1000, 1023, 1024, 4096, 16384, 60000, 65536]:
         assert lib.pda_opt_n_threads(n) == oracle.opt_n_threads(n)
+
+
+def test_wgrad_form_query(lib):
+    """Host-side dispatch rule of pda_linear_wgrad (include/pda_train.h): narrow layers stream, wide layers with enough work
+    take the split-bf16 kernel, the rest the f32-MFMA split-K kernel; the scratch size follows the same rule."""
+    form = lambda t, i, o: lib.pda_linear_wgrad_form(t, i, o)
+    assert form(1048576, 32, 64) == 1 and form(8192, 64, 64) == 1
+    assert form(131072, 512, 512) == 2 and form(62517, 512, 1536) == 2 and form(32768, 256, 256) == 2
+    assert form(12979, 256, 256) == 0          # too little work for 256 KB of partials per workgroup
+    assert form(131072, 256, 128) == 0 and form(131072, 260, 256) == 0 and form(4000, 512, 1536) == 0
+    for t, i, o in [(131072, 512, 512), (12979, 256, 256), (1048576, 32, 64)]:
+        assert lib.pda_linear_wgrad_scratch_bytes(t, i, o) >= (i * o + o) * 4
 
 
 def test_argument_validation_without_gpu(lib):

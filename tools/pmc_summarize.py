@@ -34,7 +34,7 @@ traffic = {"_how": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate pass
                    "(gfx950: FETCH_SIZE counts half of wide coalesced reads).",
            "csrc_sha1": {f: sha(f) for f in ("fps.hip", "ball_query.hip", "ball_query_cells.hip", "wgrad.hip")}, "kernels": {}}
 for target, key in (("fps", "pda::fps_chain_kernel FPS 16384->4096 b2"), ("ball_query", "pda::ball_query 16384x16384 r2 b2"),
-                    ("wgrad", "pda::wgrad_kernel dW(512x512) over 131072 tokens")):
+                    ("wgrad", "pda::linear_wgrad dW(512x512) over 131072 tokens")):
     f, fk = per_call(os.path.join(dst, "fetch_size_%s.csv" % target), "FETCH_SIZE", CALLS)
     w, wk = per_call(os.path.join(dst, "write_size_%s.csv" % target), "WRITE_SIZE", CALLS)
     if f is None or w is None:
@@ -52,7 +52,7 @@ for target in ("wgrad", "sa_mlp", "lin_cols", "lin_split", "gemm_split"):
     agg = collections.OrderedDict()
     for x in rows(os.path.join(dst, "mfma_busy_%s.csv" % target)):
         name = x["Kernel_Name"]
-        if not any(k in name for k in ("wgrad_kernel", "sa_mlp_kernel", "lin_cols_kernel", "lin_split_kernel", "gemm_split_wide_kernel", "gemm_split_kernel")):
+        if not any(k in name for k in ("wgrad_kernel", "wgrad_split_kernel", "sa_mlp_kernel", "lin_cols_kernel", "lin_split_kernel", "gemm_split_wide_kernel", "gemm_split_kernel")):
             continue
         key = "%s grid=%s" % (name.split("(")[0].replace("void ", ""), x["Grid_Size"])
         d = agg.setdefault(key, {"n": collections.Counter(), "v": collections.Counter(), "ns": 0.0})

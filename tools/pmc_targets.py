@@ -3,7 +3,7 @@
 (tools/pmc_passes.sh).  Targets and the bench keys they feed (benchmarks/workloads.py pmc_record):
   fps          FPS 16384 -> 4096, 2 scenes                  -> traffic["pda::fps_chain_kernel FPS 16384->4096 b2"]
   ball_query   layer-0 ball query 16384 x 16384, 2 radii    -> traffic["pda::ball_query 16384x16384 r2 b2"]
-  wgrad        dW(512x512) over 131072 tokens               -> traffic[...], mfma_util["pda::wgrad_kernel ..."]
+  wgrad        dW(512x512) over 131072 tokens               -> traffic[...], mfma_util["pda::wgrad_split_kernel ..."]
   sa_mlp       fused SA scale 259->256->512->512, ns 64     -> mfma_util["pda::sa_mlp_kernel ..."]
   lin_cols     training-form contraction 512->512, 131072 tokens -> mfma_util["pda::lin_cols_kernel ..."]
   lin_split    the same contraction on the split-bf16 kernel     -> mfma_util["pda::lin_split_kernel ..."]
