@@ -522,7 +522,11 @@ static void wgrad_plan(int64_t T, int M, int N, int& tiles_m, int& tiles_n, int&
     tiles_m = divup(M, WG_TILE); tiles_n = divup(N, WG_TILE);
     const int tiles = tiles_m * tiles_n;
     int64_t s = 512 / tiles;                       // ~2 workgroups per CU
-    const int64_t max_s = T / 256 > 0 ? T / 256 : 1;  // at least 256 token rows per slice
+    // few tokens: every workgroup writes 64 KB of partials whatever its slice, and 512 of them are 32 MB to write and to sum
+    // -- one workgroup per CU once a slice would be under 128 rows; never under 64 rows (two chunks) per slice.  (A slice
+    // of 256 rows is 14 us of f32 MFMA on its 128 x 128 tile: that floor made 8192-token layers take 27 us.)
+    if (T / s < 128 && tiles <= 256) s = 256 / tiles;
+    const int64_t max_s = T / 64 > 0 ? T / 64 : 1;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     KS = divup64(divup64(T, s), WG_KC) * WG_KC;

@@ -451,16 +451,20 @@ def densitynet(dn, x):
 
 
 class LinearLongTokens(Function):
-    """y = x W^T + b over the last dim of x (..., in).  Forward and the input gradient are the library GEMMs
-    (F.linear / matmul); the weight and bias gradients -- GEMMs with a tiny output and a reduction over all
-    tokens, which the libraries run at a fraction of their peak -- come from csrc/wgrad.hip in one pass."""
-    MIN_TOKENS = 32768
+    """y = x W^T + b over the last dim of x (..., in).  Forward and the input gradient are _gemm_nt / _gemm_nn (the
+    split-bf16 kernels, or the library where those do not apply); the weight and bias gradients -- GEMMs with a tiny
+    output and a reduction over all tokens, which the libraries run at a fraction of their peak -- come from
+    csrc/wgrad.hip in one pass."""
+    MIN_TOKENS = 4096
+    SPLIT_MIN_TOKENS = 32768      # forward / input gradient below this: the library (measured: the step got 0.6 ms slower with the
+                                  # 4096..32768-token layers on the split kernels and their weight-packing launches)
 
     @staticmethod
     def supported(x, weight):
-        """Where the kernel wins on MI355X (profiles/r01_wgrad_microbench.txt): both feature dims >= 128 (its
-        128 x 128 output tile is mostly empty below that) and an output small enough that the tuned library
-        GEMM cannot fill the chip: <= 256 x 768, or <= 512 x 512 with >= 65536 tokens."""
+        """Where the kernel wins on MI355X: both feature dims >= 128 (its 128 x 128 output tile is mostly empty below
+        that; <= 64 takes the streaming form) from 4096 tokens -- device time per call, library g^T x plus the bias sum
+        against pda_linear_wgrad (profiles/r02_wgrad_small_tokens.txt): 8192 x 128 -> 256: 64 / 22 us, 4096 x 256 -> 512:
+        43 / 30, 4096 x 512 -> 1536: 80 / 82, 12979 x 256 -> 256: 109 / 31."""
         return torch.is_grad_enabled() and not torch.is_autocast_enabled() and LinearLongTokens.kernel_wins(x, weight)
 
     @staticmethod
@@ -473,14 +477,14 @@ class LinearLongTokens(Function):
             return False
         if max(n_out, n_in) <= 64:       # narrow layers: the streaming form (wgrad_skinny_kernel), 3-7x the library
             return tokens >= 8192
-        if min(n_out, n_in) < 128 or tokens < LinearLongTokens.MIN_TOKENS:
-            return False
-        return n_out * n_in <= 256 * 768 or (n_out * n_in <= 512 * 512 and tokens >= 65536)
+        return min(n_out, n_in) >= 128 and tokens >= LinearLongTokens.MIN_TOKENS
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        if x.numel() // x.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS:
+            return torch.nn.functional.linear(x, weight, bias)
         return _gemm_nt(x.reshape(-1, x.shape[-1]), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
     @staticmethod
@@ -489,7 +493,10 @@ class LinearLongTokens(Function):
         grad_out = grad_out.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            gx = _gemm_nn(grad_out.reshape(-1, grad_out.shape[-1]), weight).view(*grad_out.shape[:-1], weight.shape[1])
+            if grad_out.numel() // grad_out.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS:
+                gx = grad_out.matmul(weight)
+            else:
+                gx = _gemm_nn(grad_out.reshape(-1, grad_out.shape[-1]), weight).view(*grad_out.shape[:-1], weight.shape[1])
         if ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2]):
             n_out, n_in = weight.shape
             xc = x.contiguous()
@@ -1115,10 +1122,10 @@ def position_mlp_ragged(layers, rppe, plan):
 def _wgrad_ragged(x2d, g2d, weight, want_bias):
     """Weight / bias gradient at the token counts of the ragged path.  They change from step to step, so no library
     selection was tuned for them, and the default heuristic runs these K = tokens reductions at 20-70 TFLOP/s where
-    csrc/wgrad.hip reaches 60-115 (profiles/r02_gemm_probe.txt); below ~8k tokens the library is ahead."""
+    csrc/wgrad.hip reaches 60-115 (profiles/r02_gemm_probe.txt), 150-200 in its split-bf16 form; below ~4k tokens the library is level."""
     n_out, n_in = weight.shape
     tokens = x2d.shape[0]
-    if (LINEAR_WGRAD_KERNEL and tokens >= 8192 and (min(n_out, n_in) >= 128 or max(n_out, n_in) <= 64) and n_out % 4 == 0
+    if (LINEAR_WGRAD_KERNEL and tokens >= 4096 and (min(n_out, n_in) >= 128 or max(n_out, n_in) <= 64) and n_out % 4 == 0
             and n_in % 4 == 0 and x2d.dtype == torch.float32 and g2d.dtype == torch.float32):
         gw = torch.empty_like(weight)
         gb = torch.empty((n_out,), dtype=torch.float32, device=x2d.device) if want_bias else None
