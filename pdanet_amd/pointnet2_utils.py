@@ -461,8 +461,8 @@ class LinearLongTokens(Function):
 
     @staticmethod
     def supported(x, weight):
-        """Where the kernel wins on MI355X: both feature dims >= 128 (its 128 x 128 output tile is mostly empty below
-        that; <= 64 takes the streaming form) from 4096 tokens -- device time per call, library g^T x plus the bias sum
+        """Where the kernel wins on MI355X: both feature dims >= 64 (half of its 128 x 128 output tile empty at 64: 8192 x
+        64 -> 128 still 16 us against 71; both <= 64 take the streaming form) from 4096 tokens -- device time per call, library g^T x plus the bias sum
         against pda_linear_wgrad (profiles/r02_wgrad_small_tokens.txt): 8192 x 128 -> 256: 64 / 22 us, 4096 x 256 -> 512:
         43 / 30, 4096 x 512 -> 1536: 80 / 82, 12979 x 256 -> 256: 109 / 31."""
         return torch.is_grad_enabled() and not torch.is_autocast_enabled() and LinearLongTokens.kernel_wins(x, weight)
@@ -477,13 +477,13 @@ class LinearLongTokens(Function):
             return False
         if max(n_out, n_in) <= 64:       # narrow layers: the streaming form (wgrad_skinny_kernel), 3-7x the library
             return tokens >= 8192
-        return min(n_out, n_in) >= 128 and tokens >= LinearLongTokens.MIN_TOKENS
+        return min(n_out, n_in) >= 64 and tokens >= LinearLongTokens.MIN_TOKENS
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
-        if x.numel() // x.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS:
+        if x.numel() // x.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS or min(weight.shape) < 128:
             return torch.nn.functional.linear(x, weight, bias)
         return _gemm_nt(x.reshape(-1, x.shape[-1]), weight, bias).view(*x.shape[:-1], weight.shape[0])
 
@@ -493,7 +493,7 @@ class LinearLongTokens(Function):
         grad_out = grad_out.contiguous()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
-            if grad_out.numel() // grad_out.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS:
+            if grad_out.numel() // grad_out.shape[-1] < LinearLongTokens.SPLIT_MIN_TOKENS or min(weight.shape) < 128:
                 gx = grad_out.matmul(weight)
             else:
                 gx = _gemm_nn(grad_out.reshape(-1, grad_out.shape[-1]), weight).view(*grad_out.shape[:-1], weight.shape[1])
@@ -1125,7 +1125,7 @@ def _wgrad_ragged(x2d, g2d, weight, want_bias):
     csrc/wgrad.hip reaches 60-115 (profiles/r02_gemm_probe.txt), 150-200 in its split-bf16 form; below ~4k tokens the library is level."""
     n_out, n_in = weight.shape
     tokens = x2d.shape[0]
-    if (LINEAR_WGRAD_KERNEL and tokens >= 4096 and (min(n_out, n_in) >= 128 or max(n_out, n_in) <= 64) and n_out % 4 == 0
+    if (LINEAR_WGRAD_KERNEL and tokens >= 4096 and (min(n_out, n_in) >= 64 or max(n_out, n_in) <= 64) and n_out % 4 == 0
             and n_in % 4 == 0 and x2d.dtype == torch.float32 and g2d.dtype == torch.float32):
         gw = torch.empty_like(weight)
         gb = torch.empty((n_out,), dtype=torch.float32, device=x2d.device) if want_bias else None
