@@ -476,7 +476,7 @@ class LinearLongTokens(Function):
         if n_out % 4 or n_in % 4:
             return False
         if max(n_out, n_in) <= 64:       # narrow layers: the streaming form (wgrad_skinny_kernel), 3-7x the library
-            return tokens >= 8192
+            return tokens >= 4096
         return min(n_out, n_in) >= 64 and tokens >= LinearLongTokens.MIN_TOKENS
 
     @staticmethod

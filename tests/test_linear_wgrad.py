@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
                                                      (62517, 512, 256, True), (70001, 256, 768, False), (131072, 256, 256, True),
                                                      (48365, 512, 1536, True), (100003, 512, 512, True),
                                                      # short token axes (64-row slices, one workgroup per CU) and a half-empty 128 x 128 tile
-                                                     (4096, 256, 512, True), (8192, 64, 128, True), (4099, 128, 64, False), (5000, 512, 1536, True)])
+                                                     (4096, 256, 512, True), (8192, 64, 128, True), (4096, 12, 64, True), (4099, 128, 64, False), (5000, 512, 1536, True)])
 def test_gradients(tokens, n_in, n_out, bias):
     from pdanet_amd import pointnet2_utils as pu
     torch.manual_seed(tokens % 1000 + n_in)
@@ -46,7 +46,7 @@ def test_dispatch_threshold_and_views():
     x = torch.randn(2, 4096, 16, 128, device="cuda", requires_grad=True)       # 131072 tokens
     assert pu.LinearLongTokens.supported(torch.randn(131072, 32, device="cuda"), torch.randn(64, 32, device="cuda"))      # narrow: streaming form
     assert not pu.LinearLongTokens.supported(torch.randn(131072, 32, device="cuda"), torch.randn(96, 32, device="cuda"))  # in between: library
-    assert not pu.LinearLongTokens.supported(torch.randn(4096, 32, device="cuda"), torch.randn(64, 32, device="cuda"))
+    assert not pu.LinearLongTokens.supported(torch.randn(2048, 32, device="cuda"), torch.randn(64, 32, device="cuda"))
     assert pu.LinearLongTokens.supported(x, conv.weight.flatten(1))
     assert not pu.LinearLongTokens.supported(x[:, :100], conv.weight.flatten(1))     # 3200 tokens: library path
     y = pu.linear(x, conv.weight.flatten(1), None)
