@@ -534,7 +534,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_pruned_kernel(const float* __
 // Measured (MI355X, 16384 -> 4096, B = 2, profiles/r02_fps_variants.txt): 6.65 samples per synchronisation (616
 // instead of 4095; the host replay build/fps_chain_sim2.py predicts exactly that), 3.82 -> 2.46 ms.  Per
 // synchronisation ~10k cycles: busiest wave's updates + refresh ~4.0k, the walk ~3.7k (a dependent chain of
-// ~490 cycles per accepted sample on one wave), two barriers and their skew ~2.5k.
+// ~490 cycles per accepted sample on one wave), two barriers and their skew ~2.5k.  The walk's two reductions
+// per sample (candidate, bounds of the reached rows) are one pass of two interleaved DPP chains since.
 constexpr int FPS_CHAIN_MAX = 16;
 constexpr int FPS_RECORDS = FPS_WAVES * 4;   // one record per row of 16 lanes (256 points)
 
@@ -651,14 +652,18 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
             float val = ra.x;
             const uint32_t rT = __builtin_bit_cast(uint32_t, ra.y);
             const float rx = ra.z, ry = ra.w, rz = rb.x, sec = rb.y;
-            float maxbound = -1.f;
+            // bounds of the invalidated rows: `sbound` from the accepted samples' own rows (wave-uniform), `lbound` per lane
+            // from the rows a sample reached -- reduced together with the candidate search of the NEXT step (one pass of
+            // two interleaved DPP chains) instead of a reduction of its own behind every sample that reaches a row
+            float sbound = -1.f, lbound = -1.f;
             float ox = 0.f, oy = 0.f, oz = 0.f;     // lane c collects sample c: one LDS write and one index store at the end
             uint32_t oT = 0u;
             const int rem = min(FPS_CHAIN_MAX, m - j);
             int c = 0;
             while (c < rem) {
-                const float cv = wave_max_f32(val);
-                if (cv < 0.f || maxbound >= cv) break;      // nothing valid left / an invalidated row may hold more
+                float cv = val, mb = lbound;
+                wave_max2_f32(cv, mb);
+                if (cv < 0.f || fmaxf(sbound, mb) >= cv) break;      // nothing valid left / an invalidated row may hold more
                 const unsigned long long eq = __ballot(val == cv);
                 uint32_t cT;
                 int wl;
@@ -680,8 +685,8 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
                 const float d = sqdist3(rx, ry, rz, sx, sy, sz);
                 const bool own = lane == wl;
                 const bool reach = d < val && !own;
-                maxbound = fmaxf(maxbound, ssec);
-                if (__ballot(reach) != 0ull) maxbound = fmaxf(maxbound, wave_max_f32(reach ? fmaxf(sec, d) : -1.f));
+                sbound = fmaxf(sbound, ssec);
+                lbound = reach ? fmaxf(lbound, fmaxf(sec, d)) : lbound;
                 val = (reach || own) ? -1.f : val;
                 ++c;
             }

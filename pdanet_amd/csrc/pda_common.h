@@ -161,6 +161,23 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     asm volatile(PDA_DPP_REDUCE64("v_max_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// Two independent maxima in one pass: the second chain fills the wait states of the first (2 x 6 DPP operations and six
+// s_nop 0 instead of 2 x (6 + six s_nop 1)).
+#define PDA_DPP_STAGE_X2(OP, CTRL)                                             \
+    OP " %0, %0, %0 " CTRL "\n\t" OP " %1, %1, %1 " CTRL "\n\ts_nop 0\n\t"
+__device__ __forceinline__ void wave_max2_f32(float& a, float& b) {
+    asm volatile("s_nop 1\n\t"
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_shr:1 row_mask:0xf bank_mask:0xf")
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_shr:2 row_mask:0xf bank_mask:0xf")
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_shr:4 row_mask:0xf bank_mask:0xf")
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_shr:8 row_mask:0xf bank_mask:0xf")
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_bcast:15 row_mask:0xa bank_mask:0xf")
+                 PDA_DPP_STAGE_X2("v_max_f32_dpp", "row_bcast:31 row_mask:0xc bank_mask:0xf")
+                 "s_nop 0"
+                 : "+v"(a), "+v"(b));
+    a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, a), 63));
+    b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, b), 63));
+}
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
     asm volatile(PDA_DPP_REDUCE64("v_min_u32_dpp") : "+v"(v));
     return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
