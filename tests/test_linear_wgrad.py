@@ -17,7 +17,9 @@ pytestmark = pytest.mark.gpu
                                                      (62517, 512, 256, True), (70001, 256, 768, False), (131072, 256, 256, True),
                                                      (48365, 512, 1536, True), (100003, 512, 512, True),
                                                      # short token axes (64-row slices, one workgroup per CU) and a half-empty 128 x 128 tile
-                                                     (4096, 256, 512, True), (8192, 64, 128, True), (4096, 12, 64, True), (4099, 128, 64, False), (5000, 512, 1536, True)])
+                                                     (4096, 256, 512, True), (8192, 64, 128, True), (4096, 12, 64, True),
+                                                     # split form at its smallest token counts: a last slice of one row, a last step of one row
+                                                     (4097, 512, 1536, True), (7953, 768, 512, False), (30529, 256, 256, True), (4099, 128, 64, False), (5000, 512, 1536, True)])
 def test_gradients(tokens, n_in, n_out, bias):
     from pdanet_amd import pointnet2_utils as pu
     torch.manual_seed(tokens % 1000 + n_in)
