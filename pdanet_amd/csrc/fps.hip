@@ -655,44 +655,46 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
             // bounds of the invalidated rows: `sbound` from the accepted samples' own rows (wave-uniform), `lbound` per lane
             // from the rows a sample reached -- reduced together with the candidate search of the NEXT step (one pass of
             // two interleaved DPP chains) instead of a reduction of its own behind every sample that reaches a row
-            float sbound = -1.f, lbound = -1.f;
-            float ox = 0.f, oy = 0.f, oz = 0.f;     // lane c collects sample c: one LDS write and one index store at the end
-            uint32_t oT = 0u;
+            // Every value compared here is >= +0.0 or exactly -1.0f, so the bit patterns order like the numbers and the
+            // wave-uniform part of the walk (bounds, stop test) runs on the scalar unit.
+            int sbound = __builtin_bit_cast(int, -1.f);
+            float lbound = -1.f;
+            int ox = 0, oy = 0, oz = 0, oT = 0;     // lane c collects sample c: one LDS write and one index store at the end
             const int rem = min(FPS_CHAIN_MAX, m - j);
             int c = 0;
             while (c < rem) {
                 float cv = val, mb = lbound;
                 wave_max2_f32(cv, mb);
-                if (cv < 0.f || fmaxf(sbound, mb) >= cv) break;      // nothing valid left / an invalidated row may hold more
+                const int cvi = __builtin_bit_cast(int, cv), mbi = __builtin_bit_cast(int, mb);
+                if (cvi < 0 || max(sbound, mbi) >= cvi) break;       // nothing valid left / an invalidated row may hold more
                 const unsigned long long eq = __ballot(val == cv);
-                uint32_t cT;
-                int wl;
+                int cT, wl;
                 if (__builtin_popcountll(eq) == 1) {
                     wl = (int)__builtin_ctzll(eq);
-                    cT = (uint32_t)__builtin_amdgcn_readlane((int)rT, wl);
+                    cT = __builtin_amdgcn_readlane((int)rT, wl);
                 } else {
-                    cT = wave_min_u32(val == cv ? rT : 0xffffffffu);
-                    wl = (int)__builtin_ctzll(__ballot(val == cv && rT == cT) | (1ull << 63));
+                    cT = (int)wave_min_u32(val == cv ? rT : 0xffffffffu);
+                    wl = (int)__builtin_ctzll(__ballot(val == cv && rT == (uint32_t)cT) | (1ull << 63));
                 }
-                const float sx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), wl));
-                const float sy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), wl));
-                const float sz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rz), wl));
-                const float ssec = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sec), wl));
+                const int sxi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rx), wl);
+                const int syi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ry), wl);
+                const int szi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, rz), wl);
+                sbound = max(sbound, __builtin_amdgcn_readlane(__builtin_bit_cast(int, sec), wl));   // its own row: bounded by its second best
                 const bool mine = lane == c;
-                ox = mine ? sx : ox; oy = mine ? sy : oy; oz = mine ? sz : oz; oT = mine ? cT : oT;
+                ox = mine ? sxi : ox; oy = mine ? syi : oy; oz = mine ? szi : oz; oT = mine ? cT : oT;
                 // which other records does this sample invalidate?  Exactly those whose best point it reaches
-                // (an invalid record has value -1: d >= 0 never reaches it again).
-                const float d = sqdist3(rx, ry, rz, sx, sy, sz);
-                const bool own = lane == wl;
-                const bool reach = d < val && !own;
-                sbound = fmaxf(sbound, ssec);
+                // (an invalid record has value -1: d >= 0 never reaches it again; the sample's own record goes first).
+                val = writelane_minus_one(wl, val);
+                const float d = sqdist3(rx, ry, rz, __builtin_bit_cast(float, sxi), __builtin_bit_cast(float, syi), __builtin_bit_cast(float, szi));
+                const bool reach = d < val;
                 lbound = reach ? fmaxf(lbound, fmaxf(sec, d)) : lbound;
-                val = (reach || own) ? -1.f : val;
+                val = reach ? -1.f : val;
                 ++c;
             }
             if (lane < c) {
-                chain[lane] = make_float4(ox, oy, oz, __builtin_bit_cast(float, oT));
-                idx[j + lane] = (int)fps_tiebreak_decode(oT, L);
+                chain[lane] = make_float4(__builtin_bit_cast(float, ox), __builtin_bit_cast(float, oy), __builtin_bit_cast(float, oz),
+                                          __builtin_bit_cast(float, oT));
+                idx[j + lane] = (int)fps_tiebreak_decode((uint32_t)oT, L);
             }
             if (lane == 0) chain_n = c;
         }

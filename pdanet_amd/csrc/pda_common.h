@@ -161,6 +161,12 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     asm volatile(PDA_DPP_REDUCE64("v_max_f32_dpp") : "+v"(v));
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
+// v[lane] = -1.0f for one wave-uniform lane (v_writelane_b32 with an inline constant: a second SGPR operand would break
+// the constant-bus limit; hipcc 7.2 has no builtin for the instruction).
+__device__ __forceinline__ float writelane_minus_one(int lane_uniform, float v) {
+    asm volatile("v_writelane_b32 %0, -1.0, %1" : "+v"(v) : "s"(lane_uniform));
+    return v;
+}
 // Two independent maxima in one pass: the second chain fills the wait states of the first (2 x 6 DPP operations and six
 // s_nop 0 instead of 2 x (6 + six s_nop 1)).
 #define PDA_DPP_STAGE_X2(OP, CTRL)                                             \
