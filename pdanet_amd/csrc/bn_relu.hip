@@ -217,15 +217,19 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const TX* __restrict__ x,
         else return load4(dy + r * s.c + 4 * col);
     };
     constexpr int U = (BWD && !POOL) ? 1 : 4;           // several strided rows per trip: see bn_reduce_kernel
+    // The rows are walked from the LAST to the first: the statistics pass before this one swept them first to last, so
+    // what the 256 MB Infinity Cache still holds is the tail of the tensors -- in the same order a tensor larger than
+    // the cache would be re-read from HBM in full.
+    const int64_t last = s.rows - 1;
     int64_t r = (int64_t)blockIdx.x * s.rpb + r0;
     for (; r + (U - 1) * stride < s.rows; r += U * stride) {
         float4 v[U], d[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { v[u] = load4(x + (r + u * stride) * s.c + 4 * col); d[u] = grad(r + u * stride); }
+        for (int u = 0; u < U; ++u) { const int64_t q = last - (r + u * stride); v[u] = load4(x + q * s.c + 4 * col); d[u] = grad(q); }
 #pragma unroll
-        for (int u = 0; u < U; ++u) row(r + u * stride, v[u], d[u]);
+        for (int u = 0; u < U; ++u) row(last - (r + u * stride), v[u], d[u]);
     }
-    for (; r < s.rows; r += stride) row(r, load4(x + r * s.c + 4 * col), grad(r));
+    for (; r < s.rows; r += stride) { const int64_t q = last - r; row(q, load4(x + q * s.c + 4 * col), grad(q)); }
 }
 
 // forward with the max-pool fused in: thread = (group, 4-channel column); y = relu(bn(x)) is never written, out (groups, C)
