@@ -192,7 +192,7 @@ def main():
             torch.cuda.empty_cache()
             xw = workloads.create(xname, xbatch, args.points, device, rank, world)
             xsteps = max(5, min(args.steps, 10))
-            xdt = time_workload(xw, xsteps, 2, device, parallel)
+            xdt = time_workload(xw, xsteps, 6, device, parallel)     # two warm-up steps left first-use costs (allocator growth, library heuristics) in the timed ones
             xr = xw.rooflines()
             extra[xname] = {"workload": xw.name, "step": step_text(xw.name), "scenes_per_gpu": xbatch,
                             "steps": xsteps, "ms_per_step": xdt / xsteps * 1e3, "scenes_per_s": xbatch * xsteps / xdt,
