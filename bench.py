@@ -173,6 +173,11 @@ def main():
     if hasattr(wl, "tuned"):
         line["config"]["hipblaslt_tunableop_results_loaded"] = bool(wl.tuned)
     line["config"]["peak_mem_GiB"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+    if hasattr(getattr(wl, "model", None), "graph_tail"):
+        # layers 3-5 + head + losses replayed as hipGraphs: chosen by the workload when the host was the limit (workloads.py)
+        line["config"]["graph_tail"] = bool(wl.model.graph_tail)
+        if hasattr(wl, "host_bound"):
+            line["config"]["host_bound_at_probe"] = bool(wl.host_bound)
 
     single = world == 1 and rank == 0
     if single and not args.no_cpu_baseline:

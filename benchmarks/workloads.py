@@ -551,8 +551,13 @@ class DetectorTrainWorkload(TrainStepWorkload):
         # rehearsal with the graphed head under DDP crashed in capture: not pursued without multi-GPU hardware)
         self.model.graph_head = world == 1 and os.environ.get("PDA_GRAPH_HEAD", "1") != "0"
         # graph_tail: layers 3-5 + head + losses as hipGraphs.  Measured: -3 ms on the host-bound dense-bf16 iteration
-        # (18.4 -> 15.4 ms), +0.4 ms on the device-bound fp32 one.
-        self.model.graph_tail = world == 1 and os.environ.get("PDA_GRAPH_TAIL", "1" if dense_bf16 else "0") != "0"
+        # (18.4 -> 15.4 ms), +0.4 ms on the fp32 one where the device is the limit -- which depends on the box: the fp32
+        # iteration takes 20.5 ms of device time and 18-23 ms of host time to enqueue (the pool's hosts differ), so the
+        # fp32 workload decides on its fourth iteration: one synchronised measurement of enqueue time against elapsed
+        # time, graph_tail on when the host is the limit (21.6 instead of 23.0 ms there).  PDA_GRAPH_TAIL=0|1 fixes it.
+        mode = os.environ.get("PDA_GRAPH_TAIL", "1" if dense_bf16 else "auto")
+        self.model.graph_tail = world == 1 and mode == "1"
+        self._tail_auto = world == 1 and mode == "auto"
         self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
         self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
@@ -565,6 +570,10 @@ class DetectorTrainWorkload(TrainStepWorkload):
         return base
 
     def step(self):
+        probe = self._tail_auto and self.it == 3
+        if probe:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
         model = self.ddp if self.ddp is not None else self.model
         self.sched.step(self.it)
         self.opt.zero_grad(set_to_none=self.ddp is None)    # DDP copies its reduced buckets into the flat-buffer views
@@ -574,6 +583,13 @@ class DetectorTrainWorkload(TrainStepWorkload):
         self.opt.step()
         self.it += 1
         self.tb = tb
+        if probe:
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            self.host_bound = (t1 - t0) > 0.93 * (t2 - t0)      # the GPU was done (almost) as soon as the host was
+            self.model.graph_tail = self.host_bound
+            self._tail_auto = False
         return ret['loss']
 
 
