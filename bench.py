@@ -147,6 +147,8 @@ def main():
     name = workloads.DEFAULT if args.workload == "auto" else args.workload
     batch = args.batch if args.batch is not None else (4 if name.startswith("kitti") else 2)
     wl = workloads.create(name, batch, args.points, device, rank, world)
+    if args.warmup < 5 and getattr(wl, "_tail_auto", False):
+        wl._tail_auto = False        # the probe (iteration 4) and the capture behind it (iteration 5) must stay out of the timed steps
     dt = time_workload(wl, args.steps, args.warmup, device, parallel)
     roofs = wl.rooflines()
 
