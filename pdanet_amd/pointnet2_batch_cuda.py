@@ -379,11 +379,17 @@ def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, s
     return 1
 
 
+_WGRAD_SCRATCH_BYTES = {}
+
+
 def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_features):
     """MI355X extension: grad_weight (out, in) = grad_out^T x and grad_bias = column sums (csrc/wgrad.hip)."""
     _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
     _numel_ok(grad_weight, in_features * out_features, "grad_weight")
-    nbytes = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    key = (tokens, in_features, out_features)
+    nbytes = _WGRAD_SCRATCH_BYTES.get(key)
+    if nbytes is None:      # ~60 weight gradients per training step: the size query is a foreign call of its own
+        nbytes = _WGRAD_SCRATCH_BYTES[key] = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     gb = None if grad_bias is None else _chk(grad_bias, "grad_bias", F32)
     _call("pda_linear_wgrad", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32),
