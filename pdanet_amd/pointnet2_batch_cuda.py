@@ -13,6 +13,8 @@ module's name set equals the reference's, and raises PdaError (PDA_ERR_UNSUPPORT
 """
 import ctypes
 
+import functools
+
 import torch
 
 from . import _lib
@@ -108,6 +110,7 @@ def ball_query_multi(b, n, m, radii, nsamples, new_xyz, xyz, idxs):
     return 1
 
 
+@functools.lru_cache(maxsize=None)
 def ball_query_cells_scratch_bytes(b, n):
     return int(_lib.load().pda_ball_query_cells_scratch_bytes(int(b), int(n)))
 
@@ -254,6 +257,7 @@ def group_attention_bwd(qkv, grad_out, lse, grad_qkv, num_groups, seq, heads, he
     return 1
 
 
+@functools.lru_cache(maxsize=None)
 def bn_relu_scratch_bytes(c):
     return int(_lib.load().pda_bn_relu_scratch_bytes(int(c)))
 
@@ -329,6 +333,7 @@ def bn_relu_max_pool_bwd(x, grad_out, arg, gamma, beta, mean_invstd, grad_x, gra
     return 1
 
 
+@functools.lru_cache(maxsize=None)
 def layer_norm_scratch_bytes(d):
     return int(_lib.load().pda_layer_norm_scratch_bytes(int(d)))
 
@@ -382,6 +387,17 @@ def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, s
 _WGRAD_SCRATCH_BYTES = {}
 
 
+@functools.lru_cache(maxsize=None)
+def _split_packed_bytes(n_out, k):
+    """Size queries are pure functions of the shape: cached, a training step asks ~300 times (each a foreign call)."""
+    return int(_lib.load().pda_linear_split_packed_bytes(n_out, k))
+
+
+@functools.lru_cache(maxsize=None)
+def _cols_packed_size(n_out, k):
+    return int(_lib.load().pda_linear_cols_packed_size(n_out, k))
+
+
 def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_features):
     """MI355X extension: grad_weight (out, in) = grad_out^T x and grad_bias = column sums (csrc/wgrad.hip)."""
     _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
@@ -406,6 +422,7 @@ def colsum_bf16(g, out, rows, cols):
     return 1
 
 
+@functools.lru_cache(maxsize=None)
 def densitynet_sizes():
     lib = _lib.load()
     return int(lib.pda_densitynet_param_count()), int(lib.pda_densitynet_scratch_bytes())
@@ -569,7 +586,7 @@ def group_attention_ragged_bwd(qkv, grad_out, lse, cnt, off, grad_qkv, tokens, n
 def linear_cols_pack(w, n_out, k, transposed_source=False, gather_order=False):
     """Packed copy of a weight matrix for linear_cols / sa_gather_linear (A-fragment order of the f32 MFMA)."""
     lib = _lib.load()
-    wf = torch.empty((int(lib.pda_linear_cols_packed_size(int(n_out), int(k))),), dtype=F32, device=w.device)
+    wf = torch.empty((_cols_packed_size(int(n_out), int(k)),), dtype=F32, device=w.device)
     _numel_ok(w, n_out * k, "w")
     _call("pda_linear_cols_pack", w, _chk(w, "w", F32), _chk(wf, "wf", F32), n_out, k, 1 if transposed_source else 0,
           1 if gather_order else 0)
@@ -578,7 +595,7 @@ def linear_cols_pack(w, n_out, k, transposed_source=False, gather_order=False):
 
 def linear_cols(x, wf, y, tokens, k, n_out):
     _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
-    _numel_ok(wf, int(_lib.load().pda_linear_cols_packed_size(int(n_out), int(k))), "wf")
+    _numel_ok(wf, _cols_packed_size(int(n_out), int(k)), "wf")
     _call("pda_linear_cols", x, _chk(x, "x", F32), _chk(wf, "wf", F32), _chk(y, "y", F32), tokens, k, n_out)
     return 1
 
@@ -586,7 +603,7 @@ def linear_cols(x, wf, y, tokens, k, n_out):
 # ---- f32 GEMM on the bf16 matrix cores, operands split into three bf16 terms (csrc/gemm_split.hip) -----------------
 def linear_split_pack(w, n_out, k, transposed_source=False):
     lib = _lib.load()
-    wf = torch.empty((int(lib.pda_linear_split_packed_bytes(int(n_out), int(k))),), dtype=torch.uint8, device=w.device)
+    wf = torch.empty((_split_packed_bytes(int(n_out), int(k)),), dtype=torch.uint8, device=w.device)
     _numel_ok(w, n_out * k, "w")
     _call("pda_linear_split_pack", w, _chk(w, "w", F32), _chk(wf, "wf", torch.uint8), n_out, k, 1 if transposed_source else 0)
     return wf
@@ -594,7 +611,7 @@ def linear_split_pack(w, n_out, k, transposed_source=False):
 
 def linear_split(x, wf, bias, y, tokens, k, n_out, relu=False):
     _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
-    _numel_ok(wf, int(_lib.load().pda_linear_split_packed_bytes(int(n_out), int(k))), "wf")
+    _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")
     if bias is not None:
         _numel_ok(bias, n_out, "bias")
     _call("pda_linear_split", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), None if bias is None else _chk(bias, "bias", F32),
@@ -605,7 +622,7 @@ def linear_split(x, wf, bias, y, tokens, k, n_out, relu=False):
 def gemm_split(x, wf, bias, y, tokens, k, n_out, relu=False, accumulate=False):
     """y (tokens, n_out) [+]= x (tokens, k) W^T [+ bias] [relu] on gemm_split_kernel (any k % 32 == 0, any n_out)."""
     _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
-    _numel_ok(wf, int(_lib.load().pda_linear_split_packed_bytes(int(n_out), int(k))), "wf")
+    _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")
     if bias is not None:
         _numel_ok(bias, n_out, "bias")
     _call("pda_gemm_split", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), None if bias is None else _chk(bias, "bias", F32),
@@ -616,7 +633,7 @@ def gemm_split(x, wf, bias, y, tokens, k, n_out, relu=False, accumulate=False):
 def sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, b, n, m, c, nsample, n_out):
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(feats_pm, b * n * c, "feats_pm")
     _numel_ok(idx, b * m * nsample, "idx"); _numel_ok(y, b * m * nsample * n_out, "y")
-    _numel_ok(wf, int(_lib.load().pda_linear_cols_packed_size(int(n_out), 3 + int(c))), "wf")
+    _numel_ok(wf, _cols_packed_size(int(n_out), 3 + int(c)), "wf")
     _call("pda_sa_gather_linear", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32), _chk(feats_pm, "feats_pm", F32),
           _chk(idx, "idx", I32), _chk(wf, "wf", F32), _chk(y, "y", F32), b, n, m, c, nsample, n_out)
     return 1
