@@ -6,8 +6,8 @@
          bench.py --gpus N --steps K --warmup W           (the driver's form: RANK/LOCAL_RANK/WORLD_SIZE from env)
 
 A step = one pass of the hot path over one per-GPU batch of synthetic scenes (ONCE, 16384 points, batch 2 per
-GPU as in the ONCE yaml; weak scaling: every rank processes its own scenes, the only exchange step is DDP's
-gradient all-reduce over RCCL).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+GPU as in the ONCE yaml; weak scaling: every rank processes its own scenes, the only exchange step is the
+gradient all-reduce over RCCL -- one collective on the optimizer's flat gradient buffer, outside autograd).  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
 Launch contract (reference: tools/scripts/torch_train.sh:17, dist_train.sh:18 start one process per GPU):
 `--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches this file under torch.distributed.run with
@@ -64,6 +64,7 @@ def spawn_ranks(args, argv):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "8")
+    env.setdefault("PYTHONFAULTHANDLER", "1")     # a rank that dies on a signal leaves its Python stack on stderr
     return subprocess.call(cmd, env=env)
 
 
@@ -168,7 +169,8 @@ def main():
         "config": {"workload": wl.name, "step": step_text(wl.name), "scenes_per_gpu": batch,
                    "global_batch": batch * world, "points_per_scene": args.points, "parallelism": "dp%d" % world,
                    "world_size_seen": seen_world, "dist_backend": backend,
-                   "gradient_exchange": "DDP all-reduce over %s" % backend if getattr(wl, "ddp", None) is not None else None},
+                   "gradient_exchange": getattr(wl, "exchange", None) or (
+                       "DDP all-reduce over %s" % backend if getattr(wl, "ddp", None) is not None else None)},
     }
     line.update({k: v for k, v in roofs.items() if v is not None})
     line.setdefault("roofline", None)
@@ -178,6 +180,7 @@ def main():
     if hasattr(getattr(wl, "model", None), "graph_tail"):
         # layers 3-5 + head + losses replayed as hipGraphs: chosen by the workload when the host was the limit (workloads.py)
         line["config"]["graph_tail"] = bool(wl.model.graph_tail)
+        line["config"]["graph_head"] = bool(getattr(wl.model, "graph_head", False))
         if hasattr(wl, "host_bound"):
             line["config"]["host_bound_at_probe"] = bool(wl.host_bound)
 

@@ -512,10 +512,29 @@ class TrainStepWorkload(BackboneWorkload):
             self.points_np = synth.batch_points(batch, n_points, config_id=3 + 10 * rank, dist="L", dataset=dataset)
             self.points = torch.from_numpy(self.points_np).to(device)
         self.name = "%s%dk_b%d_backbone_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
-        self.opt = optimization.build_optimizer(self.model, self.OPTIM)     # flat buffers BEFORE DDP
+        self.opt = optimization.build_optimizer(self.model, self.OPTIM)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.OPTIM)
-        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
+        self._data_parallel(world)
         self.it = 0
+
+    def _data_parallel(self, world):
+        """The gradient exchange of tools/train.py:153-154.  Default: one all-reduce of the optimizer's flat gradient buffer
+        between backward and the clipping norm (optimization.FlatAdamOneCycle.data_parallel) -- no autograd hooks, so the
+        N-rank step is the 1-rank step plus one collective.  PDA_DDP=1: the reference-shaped DistributedDataParallel wrapper
+        (reducer hooks, bucket -> view copy per step; eager head, because hooks must not fire inside a captured region)."""
+        from pdanet_amd import parallel
+        self.ddp, self.exchange = None, None
+        if world == 1:
+            return
+        if os.environ.get("PDA_DDP") == "1":
+            self.model.graph_head = self.model.graph_tail = False
+            self._tail_auto = False
+            self.ddp = parallel.wrap_ddp(self.model, self.device, grads_are_views=True)
+            self.exchange = "DistributedDataParallel (reducer hooks in backward, 25 MB buckets)"
+        else:
+            self.opt.data_parallel(model=self.model)
+            self.exchange = "one all-reduce (%s) of the flat fp32 gradient buffer (%.1f MB) between backward and the clipping " \
+                            "norm, outside autograd" % ("AVG" if self.opt._dp_avg else "SUM + scale", self.opt.flat_g.numel() * 4 / 1e6)
 
     def step(self):
         model = self.ddp if self.ddp is not None else self.model
@@ -547,20 +566,20 @@ class DetectorTrainWorkload(TrainStepWorkload):
         model, self.cfg = detector.build_detector(cfg)
         self.model = model.to(device).train()
         self.name = "%s%dk_b%d_detector_fwd_bwd_adam%s" % (dataset, n_points // 1024, batch, "_bf16" if dense_bf16 else "")
-        # head + losses replayed as hipGraphs (detector.IASSD.graph_head); DDP runs keep the eager head (a two-rank
-        # rehearsal with the graphed head under DDP crashed in capture: not pursued without multi-GPU hardware)
-        self.model.graph_head = world == 1 and os.environ.get("PDA_GRAPH_HEAD", "1") != "0"
+        # head + losses replayed as hipGraphs (detector.IASSD.graph_head), at every world size: the gradient exchange is
+        # outside autograd (_data_parallel), so nothing of it can land inside a captured region
+        self.model.graph_head = os.environ.get("PDA_GRAPH_HEAD", "1") != "0"
         # graph_tail: layers 3-5 + head + losses as hipGraphs.  Measured: -3 ms on the host-bound dense-bf16 iteration
         # (18.4 -> 15.4 ms), +0.4 ms on the fp32 one where the device is the limit -- which depends on the box: the fp32
         # iteration takes 20.5 ms of device time and 18-23 ms of host time to enqueue (the pool's hosts differ), so the
         # fp32 workload decides on its fourth iteration: one synchronised measurement of enqueue time against elapsed
         # time, graph_tail on when the host is the limit (21.6 instead of 23.0 ms there).  PDA_GRAPH_TAIL=0|1 fixes it.
         mode = os.environ.get("PDA_GRAPH_TAIL", "1" if dense_bf16 else "auto")
-        self.model.graph_tail = world == 1 and mode == "1"
-        self._tail_auto = world == 1 and mode == "auto"
+        self.model.graph_tail = mode == "1"
+        self._tail_auto = mode == "auto"
         self.opt = optimization.build_optimizer(self.model, self.cfg.OPTIMIZATION)
         self.sched = optimization.build_scheduler(self.opt, 1000, 80, self.cfg.OPTIMIZATION)
-        self.ddp = parallel.wrap_ddp(self.model, device, grads_are_views=True) if world > 1 else None
+        self._data_parallel(world)
         self.it = 0
 
     def cpu_baseline(self, budget_s=30.0):

@@ -105,8 +105,6 @@ class FlatAdamOneCycle:
         if not everything:
             raise ValueError("model has no trainable parameters")
         dev = everything[0].device
-        if dev.type != "cuda":
-            raise _lib.PdaError("FlatAdamOneCycle needs the parameters on the GPU (no CPU path)")
         self.offsets, off = [], 0
         for p in everything:
             if p.dtype != torch.float32 or p.device != dev:
@@ -134,6 +132,49 @@ class FlatAdamOneCycle:
         self.wd, self.beta2, self.eps, self.grad_norm_clip = wd, beta2, eps, grad_norm_clip
         self.lr, self.mom = lr, mom
         self.step_count = 0
+        self._dp_group, self._dp_world, self._dp_avg = None, 1, False
+
+    # ---- data parallel: the gradient exchange of tools/train.py:153-154 (DDP), outside autograd ----------------
+    def data_parallel(self, group=None, sync_parameters=True, model=None):
+        """Make step() all-reduce the flat gradient buffer over `group` (default: the world) before the norm.
+
+        The reference wraps the model in DistributedDataParallel, whose reducer hooks fire inside backward.  Here the
+        whole gradient already is ONE fp32 buffer, so the exchange is one collective on it between backward and the
+        clipping norm: no hooks (nothing of the exchange can end up inside a captured hipGraph region, so N ranks run the
+        same graphed step as one rank), no buckets and no bucket -> view copy, .grad stay views of the flat buffer.
+        RCCL averages in the collective (ReduceOp.AVG: no extra launch); backends without AVG (gloo) sum, then one scale
+        launch.  25.5 MB per rank: latency-bound on xGMI.  sync_parameters: broadcast rank 0's parameters (and, with
+        `model`, its buffers and untrained parameters) once, as DDP does at construction.  Not reproduced: DDP's
+        per-forward broadcast of BatchNorm running statistics -- training-mode forwards never read them and rank 0
+        writes the checkpoint, so rank 0's statistics are what a DDP run would have kept too."""
+        import torch.distributed as dist
+        if not dist.is_initialized() or dist.get_world_size(group) == 1:
+            return self
+        self._dp_group, self._dp_world = group, dist.get_world_size(group)
+        self._dp_avg = dist.get_backend(group) == "nccl"
+        if sync_parameters:
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            dist.broadcast(self.flat_p, src, group=group)
+            if model is not None:
+                mine = {id(p) for p in self.params}
+                for t in [p.data for p in model.parameters() if id(p) not in mine] + list(model.buffers()):
+                    dist.broadcast(t, src, group=group)
+            _lib.PARAM_EPOCH[0] += 1
+        return self
+
+    def exchange_gradients(self):
+        """Mean of flat_g over the ranks, in place, on the current stream (called by step(); public for loops that
+        clip or log between backward and step)."""
+        import torch.distributed as dist
+        if self._gather:
+            self._gather_grads()
+        if self._dp_world == 1:
+            return
+        if self._dp_avg:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.AVG, group=self._dp_group)
+        else:
+            dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self._dp_group)
+            self.flat_g.mul_(1.0 / self._dp_world)
 
     def zero_grad(self, set_to_none=False):
         """Default: zero the flat gradient buffer; `.grad` stay views of it, so autograd ACCUMULATES into them (one small
@@ -166,9 +207,15 @@ class FlatAdamOneCycle:
 
     def step(self):
         """clip_grad_norm_(model.parameters(), GRAD_NORM_CLIP) + OptimWrapper.step()."""
+        if self.flat_p.device.type != "cuda":
+            # the flat buffers and the gradient exchange are plumbing and work anywhere (the gloo tests build them on the
+            # CPU); the update itself is csrc/optim.hip and nothing else
+            raise _lib.PdaError("FlatAdamOneCycle.step needs the parameters on the GPU (no CPU path)")
         lib = _lib.load()
         if self._gather:
             self._gather_grads()
+        if self._dp_world > 1:
+            self.exchange_gradients()
         stream = torch.cuda.current_stream(self.flat_p.device).cuda_stream
         with torch.cuda.device(self.flat_p.device):
             norm_ptr = None

@@ -44,16 +44,35 @@ def test_gpus_n_spawns_n_ranks_before_touching_the_gpu(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_two_ranks_on_one_card_report_world_size_2():
-    """The whole --gpus 2 path of bench.py (self-spawn -> torch.distributed.run -> DDP gradient all-reduce -> MAX over
-    ranks -> one JSON line) with both ranks on the one GPU of the box over gloo (RCCL refuses two ranks per device)."""
-    env = dict(os.environ, PDA_REHEARSE_ONE_GPU="1", PDA_DIST_BACKEND="gloo")
+@pytest.mark.parametrize("tail", ["0", "1"])
+def test_two_ranks_on_one_card_report_world_size_2(tail):
+    """The whole --gpus 2 path of bench.py (self-spawn -> torch.distributed.run -> flat-buffer gradient all-reduce -> MAX
+    over ranks -> one JSON line) with both ranks on the one GPU of the box over gloo (RCCL refuses two ranks per device).
+    The ranks run the SAME graphed step as a single rank: head + losses (tail = 0) or layers 3-5 + head + losses (tail = 1)
+    replayed as hipGraphs, the gradient exchange outside every captured region (round 2 crashed here under DDP)."""
+    env = dict(os.environ, PDA_REHEARSE_ONE_GPU="1", PDA_DIST_BACKEND="gloo", PDA_GRAPH_TAIL=tail, PYTHONFAULTHANDLER="1")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0", "--points", "4096",
+    env.pop("PDA_GRAPH_HEAD", None)
+    env.pop("PDA_DDP", None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "4096",
                         "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["world_size_seen"] == 2 and d["config"]["global_batch"] == 4
-    assert d["config"]["gradient_exchange"] and d["value"] > 0 and d["scaling"] == "weak"
+    assert "flat fp32 gradient buffer" in d["config"]["gradient_exchange"] and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["config"]["graph_head"] is True and d["config"]["graph_tail"] is (tail == "1")
+
+
+@pytest.mark.gpu
+def test_two_ranks_reference_shaped_ddp_path():
+    """PDA_DDP=1 keeps the reference's DistributedDataParallel wrapper (tools/train.py:153-154) available: eager head."""
+    env = dict(os.environ, PDA_REHEARSE_ONE_GPU="1", PDA_DIST_BACKEND="gloo", PDA_DDP="1", PYTHONFAULTHANDLER="1")
+    env.pop("WORLD_SIZE", None)
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0", "--points", "4096",
+                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-4000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and "DistributedDataParallel" in d["config"]["gradient_exchange"]
+    assert d["config"]["graph_head"] is False and d["config"]["graph_tail"] is False
