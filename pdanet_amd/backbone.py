@@ -136,7 +136,9 @@ class IASSD_Backbone(nn.Module):
                 if pre is not None:
                     keep += list(pre['idxs'])
                     for part in (pre['parts'] or []):
-                        keep += list(part[:3])
+                        # every device tensor of the plan (cnt, off, rowmap AND roww): all are allocated on this side stream,
+                        # read by main-stream kernels and some saved for backward
+                        keep += [t for t in part if torch.is_tensor(t)]
                 for t in keep:
                     t.record_stream(main)
                 out[i] = (ev, idx, new_xyz, pre)

@@ -67,12 +67,27 @@ __global__ __launch_bounds__(1024) void bqc_grid_kernel(const float* __restrict_
     int nc[3];
     const float ext[3] = {hi[0] - lo[0], hi[1] - lo[1], hi[2] - lo[2]};
     const int thin = (ext[2] <= ext[0] && ext[2] <= ext[1]) ? 2 : (ext[1] <= ext[0] ? 1 : 0);
-    for (;;) {   // bounded: every pass grows an edge by >= 26 %
+    // A scene with a non-finite coordinate has no finite bounding box (ext = inf or NaN keeps nc at its cap however far the
+    // edges grow): ONE cell for the whole scene, i.e. every centre tests every point -- the reference's scan, in which a
+    // non-finite point is never a hit (inf < r2 and NaN < r2 are false).  Bit test: the build sets -fno-honor-nans.
+    bool finite = true;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) finite = finite && (__float_as_uint(ext[a]) & 0x7f800000u) != 0x7f800000u;
+    bool fits = false;
+    for (int pass = 0; finite && pass < 400; ++pass) {   // every pass grows an edge by >= 26 %: 400 passes cover any float extent
 #pragma unroll
         for (int a = 0; a < 3; ++a) nc[a] = (int)fminf(floorf(ext[a] / g[a]), 32766.f) + 1;
-        if ((int64_t)nc[0] * nc[1] * nc[2] <= max_cells) break;
+        if ((int64_t)nc[0] * nc[1] * nc[2] <= max_cells) { fits = true; break; }
         if (nc[thin] > 1) g[thin] *= 2.0f;
         else { g[0] *= 1.26f; g[1] *= 1.26f; g[2] *= 1.26f; }
+    }
+    if (!fits) {
+        BqcGrid one;
+        one.ox = one.oy = one.oz = 0.f;
+        one.inv_gx = one.inv_gy = one.inv_gz = 0.f;      // every finite coordinate maps to cell 0
+        one.nx = one.ny = one.nz = one.ncell = 1;
+        grids[blockIdx.x] = one;
+        return;
     }
     BqcGrid gr;
     gr.ox = lo[0]; gr.oy = lo[1]; gr.oz = lo[2];

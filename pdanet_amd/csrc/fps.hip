@@ -867,7 +867,8 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
         // K workgroups per scene, all resident together: a launch holds at most what the device admits at once
         // (one 1024-lane workgroup per CU for this kernel; the occupancy query only confirms >= 1) and 64 scenes
         static std::atomic<uint32_t> epoch_counter{1};
-        static const int resident = coop_resident_workgroups();
+        static PerDevice<int> resident_of;
+        const int resident = resident_of.get(coop_resident_workgroups);
         const int K = divup(n, 16384);
         const int chunk = std::min(FPS_XBUF_SCENES, resident / K);
         if (chunk >= 1) {

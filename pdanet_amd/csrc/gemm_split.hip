@@ -600,8 +600,9 @@ PDA_API int pda_gemm_split(const float* x, const void* wf, const float* bias, fl
     static const int force = getenv("PDA_GEMM_SPLIT_TILE") ? atoi(getenv("PDA_GEMM_SPLIT_TILE")) : 0;
     const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
     if (force == 256 || (force != 128 && wide_blocks >= 200 && (p.chunks % 2 == 0 || p.chunks >= 5))) {
-        static const bool ok = hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   2 * pda::GW_TILE_U4 * 16) == hipSuccess;
+        static pda::PerDevice<bool> lds_ok;
+        const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   2 * pda::GW_TILE_U4 * 16) == hipSuccess; });
         if (ok) {
             hipLaunchKernelGGL(pda::gemm_split_wide_kernel, dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16,
                                (hipStream_t)stream, p);

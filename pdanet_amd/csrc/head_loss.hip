@@ -129,7 +129,8 @@ __global__ __launch_bounds__(HL_THREADS) void head_box_loss_kernel(const float* 
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
             const float cw = code_w ? code_w[k] : 1.f;
-            const float t = l[k] != l[k] ? x[k] : l[k];       // NaN targets follow the input (loss_utils.py:166)
+            // NaN targets follow the input (loss_utils.py:166).  Bit test: -fno-honor-nans lets the compiler fold l != l
+            const float t = (__float_as_uint(l[k]) & 0x7fffffffu) > 0x7f800000u ? x[k] : l[k];
             float dd;
             rl += hl_smooth_l1((x[k] - t) * cw, beta, dd);
             g[k] = box_w * w * dd * cw;

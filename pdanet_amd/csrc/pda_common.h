@@ -1,6 +1,7 @@
 // pda_common.h -- shared host/device helpers for libpda_pointnet2.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdarg.h>
@@ -38,6 +39,25 @@ inline int check_launch(const char* what) {
     }
     return PDA_OK;
 }
+
+// Once-per-DEVICE host-side initialisation (a function attribute, an occupancy query): function-local statics are
+// evaluated for whichever device is current first, but a process may drive several devices.  `slot` is a function-local
+// `static pda::PerDevice<T>`; get() runs `init` the first time the CURRENT device asks (races re-run it: idempotent).
+template <typename T> struct PerDevice {
+    static constexpr int MAX_DEV = 64;
+    T value[MAX_DEV];
+    std::atomic<bool> done[MAX_DEV];
+    PerDevice() { for (int i = 0; i < MAX_DEV; ++i) done[i].store(false); }
+    template <typename F> T get(F init) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return init();
+        if (!done[dev].load(std::memory_order_acquire)) {
+            value[dev] = init();
+            done[dev].store(true, std::memory_order_release);
+        }
+        return value[dev];
+    }
+};
 
 inline int divup(int a, int b) { return (a + b - 1) / b; }
 inline int64_t divup64(int64_t a, int64_t b) { return (a + b - 1) / b; }

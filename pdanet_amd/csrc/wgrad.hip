@@ -602,8 +602,9 @@ PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_
         const int nblocks = S * tm * tn;
         float* part_w = (float*)scratch;
         float* part_b = part_w + (size_t)S * N * M;
-        static const bool ok = hipFuncSetAttribute((const void*)pda::wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                   2 * pda::WSP_TILE_U4 * 16) == hipSuccess;
+        static pda::PerDevice<bool> lds_ok;
+        const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                                   2 * pda::WSP_TILE_U4 * 16) == hipSuccess; });
         PDA_REQUIRE(ok, "pda_linear_wgrad: %d bytes of dynamic LDS refused", 2 * pda::WSP_TILE_U4 * 16);
         hipLaunchKernelGGL(pda::wgrad_split_kernel, dim3(pda::divup(nblocks, 8) * 8), dim3(512), 2 * pda::WSP_TILE_U4 * 16, st,
                            x, grad_out, part_w, grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks);

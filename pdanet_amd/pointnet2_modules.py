@@ -620,6 +620,12 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         if len(self.groupers) == 0 or not isinstance(self.groupers[0], pointnet2_utils.QueryAndGroup_alone_grouped_density_directional):
             return False
         probe = features if features is not None else next(self.parameters())
+        # repeated tokens are identical only without dropout (PDA-SSD: 0.0, :632); a config that trains with dropout keeps
+        # the dense encoder, whose own guard (transformer_block) then applies
+        tr0 = self.Local_pointformer[0]
+        if self.training and any(float(p) != 0.0 for tr in self.Local_pointformer
+                                 for p in (tr.self_attn.dropout, tr.dropout.p, tr.dropout1.p, tr.dropout2.p)):
+            return False
         return (pointnet2_utils.RaggedTransformerBlock.supported(self.Local_pointformer[0].self_attn.embed_dim,
                                                                  self.Local_pointformer[0].self_attn.num_heads, max(self.nsamples), probe)
                 and all(ns in pointnet2_utils.GroupAttention.SUPPORTED_SEQ for ns in self.nsamples)

@@ -81,3 +81,18 @@ def test_operator_uses_cells_for_large_clouds_and_matches_brute_force(ext, oracl
         pu.BALL_QUERY_CELLS = True
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf])
+def test_cells_scene_with_a_non_finite_point_terminates_and_matches(ext, oracle, bad):
+    """A scene holding one +/-inf coordinate has no finite bounding box: the grid sizing must not spin (it did: one
+    thread looped for ever at N = 16384) and the rows must still be the reference's, in which such a point is never a
+    hit (inf < r^2 is false).  Only scene 1 is affected; scene 0 keeps its normal grid."""
+    xyz = cloud(2, 16384, seed=77, dist="L")
+    xyz[1, 1234, 0] = bad
+    xyz[1, 9, 2] = bad
+    rng = np.random.default_rng(3)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.permutation(16384)[:512]])
+    new_xyz[1, new_xyz[1, :, 0] == bad] = 0.0
+    new_xyz[~np.isfinite(new_xyz)] = 0.0
+    cells_vs_oracle(ext, oracle, new_xyz, xyz, [0.8, 1.6], [16, 32])

@@ -198,3 +198,33 @@ def test_fused_loss_kernels_equal_the_torch_formulation(tag):
     for k in gt_:
         assert (gf[k] - gt_[k]).abs().max().item() <= 2e-5 * max(1.0, gt_[k].abs().max().item()), k
     assert gf["centers"].abs().max().item() > 0
+
+
+@pytest.mark.gpu
+def test_box_loss_kernel_nan_targets_follow_the_input():
+    """WeightedSmoothL1Loss replaces NaN targets by the input (loss_utils.py:166): zero loss and zero gradient on that
+    code, finite everywhere else.  The library is built with -fno-honor-nans, so the kernel tests the bit pattern."""
+    import torch.nn.functional as F
+    from pdanet_amd import loss_utils, roiaware_pool3d_utils
+    g = torch.Generator().manual_seed(5)
+    n, nb = 257, 12
+    preds = torch.randn(n, 6 + 2 * nb, generator=g).cuda().requires_grad_(True)
+    labels = torch.randn(n, 8, generator=g)
+    labels[:, 6] = torch.randint(0, nb, (n,), generator=g).float()
+    labels[::3, 1] = float("nan")
+    labels[5::7, 4] = float("nan")
+    labels = labels.cuda()
+    cls = (torch.rand(n, generator=g) > 0.4).long().cuda()
+    cw = torch.ones(6).cuda()
+    loss, l_xyz, l_bin, l_res = roiaware_pool3d_utils.head_box_loss(preds, labels, cls, cw, 1.0 / 9.0, nb, 1.0, 1.0)
+    loss.backward()
+    assert torch.isfinite(loss) and torch.isfinite(preds.grad).all()
+    pos = cls > 0
+    nan_rows = torch.isnan(labels[:, 1])
+    assert (preds.grad[nan_rows, 1] == 0).all() and preds.grad[pos & ~nan_rows, 1].abs().max() > 0
+    p2 = preds.detach().clone().requires_grad_(True)
+    w = pos.float() / torch.clamp(pos.sum().float(), min=1.0)
+    ref = loss_utils.WeightedSmoothL1Loss(beta=1.0 / 9.0, code_weights=[1.0] * 6).cuda()(p2[None, :, :6], labels[None, :, :6], weights=w[None]).sum()
+    assert float(l_xyz) == pytest.approx(float(ref), rel=2e-5)
+    ref.backward()
+    assert (preds.grad[:, :6] - p2.grad[:, :6]).abs().max().item() <= 2e-6

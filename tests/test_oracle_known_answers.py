@@ -254,3 +254,12 @@ def test_chamfer_semantics(oracle):
     assert oracle.chamfer_backward(xyz1, xyz2, g1, g2, gd1, gd2, i1, i2) == 1
     assert g1[0, 0].tolist() == [-2.0, 0.0, 0.0] and g1[0, 1].tolist() == [1.0, 0.0, 0.0]
     assert g2[0, 3].tolist() == [2.0, 0.0, 0.0] and g2[0, 600].tolist() == [-1.0, 0.0, 0.0]
+
+
+def test_ball_query_non_finite_point_is_never_a_hit(oracle):
+    """ball_query_gpu.cu:33-34: d2 = inf (or NaN) fails `d2 < radius2`, so a point with an inf coordinate is skipped."""
+    xyz = np.array([[[0, 0, 0], [np.inf, 0, 0], [0.5, 0, 0], [0, -np.inf, 0]]], np.float32)
+    new_xyz = np.array([[[0, 0, 0]]], np.float32)
+    idx = np.zeros((1, 1, 4), np.int32)
+    oracle.ball_query_wrapper(1, 4, 1, 1.0, 4, new_xyz, xyz, idx)
+    assert idx.tolist() == [[[0, 2, 0, 0]]]
