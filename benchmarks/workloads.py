@@ -16,6 +16,8 @@ DEFAULT = "detector_train"
 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (v_mfma_f32_32x32x2_f32) = the f32 vector peak
+BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
+SPLIT_PRODUCTS = 6          # csrc/split_bf16.h: an f32 product block = 6 bf16 MFMA blocks (3-term operands, 6 of 9 products)
 # plain (non-packed) VALU lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  A ball-query
 # distance test is 7 VALU instructions (3 sub, 1 mul, 2 fma, 1 compare), none of them packable without losing
 # the reference's float expression, so the VALU bound is VALU_LANE_OPS / 7 tests per second.
@@ -170,44 +172,50 @@ class KernelTimers:
                         "test; the cell-list call is 5 launches (grid, count, scan, scatter, query) timed together"}
 
     def roofline_sa_mlp_train(self):
-        """The vanilla-SA group MLPs in training form on lin_cols_kernel (forward and input-gradient contractions of ONCE
-        layers 0 and 5; the weight gradients are wgrad_kernel launches and appear in roofline_mfma): algorithmic flops of
-        all launches of the timed region / their summed duration."""
+        """The vanilla-SA group MLPs in training form (forward and input-gradient contractions of ONCE layers 0 and 5; the
+        weight gradients are csrc/wgrad.hip launches and appear in roofline_mfma).  The fraction is taken on the pipe the
+        kernels really issue on: the split GEMMs run six v_mfma_f32_32x32x16_bf16 per f32 product block, so their MFMA work
+        is 6 x the algorithmic flops, against the dense bf16 peak.  The gather-fused first layers (f32-input MFMA) are
+        reported beside it against the f32 MFMA peak."""
         if not self.sa_mfma_events:
             return None
-        t = sum(e0.elapsed_time(e1) for e0, e1, _ in self.sa_mfma_events) * 1e-3
-        fl = sum(f for _, _, f in self.sa_mfma_events)
         steps = max(1, len(self.fps_events))
-        from pdanet_amd import pointnet2_utils as pu
-        split = bool(getattr(pu, "SPLIT_GEMM", False))
-        if split:
-            util = (pmc_record("mfma_util", "pda::gemm_split_wide_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns")
-                    or pmc_record("mfma_util", "pda::lin_split_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns"))
-            kern, note = "gemm_split_wide_kernel (K = 512) + lin_split_kernel (K = 256) + lin_cols_kernel<gather>", (
-                "f32 contractions on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 terms (x = h + m + l "
-                "exactly; 6 of 9 products kept, error below the f32 fmaf chain's: tests/test_gemm_split.py); peak = the f32 "
-                "MFMA peak the same contraction had before (a fraction above 1 means faster than any f32-input MFMA kernel "
-                "can be); the bf16 pipe's ceiling for this form is 2500/6 = 416.7 TFLOP/s f32-equivalent "
-                "(frac_of_split_ceiling); the gather-fused first layers stay on lin_cols_kernel (f32 MFMA); launches "
-                "include the weight-packing kernel; PDA_SPLIT_GEMM=0 restores lin_cols_kernel everywhere")
-        else:
+
+        def part(pipe):
+            ev = [e for e in self.sa_mfma_events if e[3] == pipe]
+            return (sum(e[0].elapsed_time(e[1]) for e in ev) * 1e-3, sum(e[2] for e in ev), len(ev))
+        ts, fs, ns_ = part("bf16x6")
+        tf, ff, nf = part("f32")
+        f32_part = None if nf == 0 else {
+            "kernel": "lin_cols_kernel / sa_gather_linear (v_mfma_f32_32x32x2_f32)", "launches_per_step": nf // steps,
+            "achieved": ff / tf / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ff / tf / 1e12 / F32_MFMA_PEAK_TF,
+            "ms_per_step": tf / steps * 1e3, "gflop_per_step": ff / steps / 1e9}
+        if ns_ == 0:            # PDA_SPLIT_GEMM=0: everything on the f32-input MFMA
             util = pmc_record("mfma_util", "pda::lin_cols_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
-            kern, note = "lin_cols_kernel", (
-                "v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction; "
-                "SURVEY 8(d): the layer-5 chain is 86.1 GFLOP per scene forward, the input gradients of layers 2-3 "
-                "add 77.5 (layer 1's 259-column input gradient stays on the library)")
-        ach = fl / t / 1e12
-        return {"kernel": "%s (SA group MLP, training form: %d launches per step, forward + input gradient)" % (
-                    kern, len(self.sa_mfma_events) // steps),
-                "bound": "mfma", "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                "frac": ach / F32_MFMA_PEAK_TF, "frac_of_split_ceiling": (ach / (2500.0 / 6.0)) if split else None,
-                "traffic": None, "ms_per_step": t / steps * 1e3,
-                "gflop_per_step": fl / steps / 1e9, "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
-                "note": note}
+            out = dict(f32_part, bound="mfma", traffic=None, mfma_busy_pmc=None if util is None else round(util["mfma_util"], 4),
+                       note="v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction")
+            out["kernel"] += " (SA group MLP, training form: forward + input gradient)"
+            return out
+        util = (pmc_record("mfma_util", "pda::gemm_split_wide_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns")
+                or pmc_record("mfma_util", "pda::lin_split_kernel", ["gemm_split.hip"], prefix=True, by="avg_ns"))
+        work = SPLIT_PRODUCTS * fs / ts / 1e12
+        return {"kernel": "gemm_split_wide_kernel / lin_split_kernel (SA group MLP, training form: %d launches per step, "
+                          "forward + input gradient)" % (ns_ // steps),
+                "bound": "mfma", "achieved": work, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": work / BF16_MFMA_PEAK_TF,
+                "achieved_f32_equiv": fs / ts / 1e12, "peak_f32_input_mfma": F32_MFMA_PEAK_TF,
+                "traffic": None, "ms_per_step": ts / steps * 1e3, "gflop_per_step": fs / steps / 1e9,
+                "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4), "f32_mfma_part": f32_part,
+                "note": "f32 contractions on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 terms (x = h + m + l "
+                        "exactly; 6 of 9 products kept, error at the f32 fmaf chain's: tests/test_gemm_split.py).  achieved = "
+                        "6 x algorithmic flops / time = the bf16 MFMA work really issued, peak = dense bf16 MFMA; "
+                        "achieved_f32_equiv = algorithmic flops / time, next to the f32-input MFMA peak the same contraction "
+                        "would be priced against without the split.  Launch times include the weight-packing kernel.  "
+                        "PDA_SPLIT_GEMM=0 restores lin_cols_kernel (f32 MFMA) everywhere"}
 
     def roofline_wgrad(self):
         """The weight-gradient kernel shape with the largest total time in the timed region: algorithmic flops
-        2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration."""
+        2*T*in*out per launch (the dW GEMM; the fused bias gradient is not counted) / mean launch duration, on the pipe
+        the kernel issues on (split form: 6 x the flops against the dense bf16 peak)."""
         by = {}
         for e in self.wgrad_events:
             by.setdefault(e[2:], []).append(e[0].elapsed_time(e[1]) * 1e-3)
@@ -219,23 +227,35 @@ class KernelTimers:
         total = sum(sum(v) for v in by.values())
         steps = max(1, len(self.fps_events))          # one D-FPS launch per step
         from pdanet_amd import _lib
-        split = int(_lib.load().pda_linear_wgrad_form(t, ni, no)) == 2
+        lib = _lib.load()
+        split = int(lib.pda_linear_wgrad_form(t, ni, no)) == 2
         kern = "wgrad_split_kernel" if split else "wgrad_kernel"
         key = "pda::linear_wgrad dW(%dx%d) over %d tokens" % (no, ni, t)
         util = pmc_record("mfma_util", "pda::" + kern, ["wgrad.hip"], prefix=True, by="launches")
-        ach = flops / avg / 1e12
-        note = ("three-term bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per f32 product block (f32 accuracy); peak = "
-                "the f32 MFMA peak the same contraction had before (a fraction above 1 means faster than any f32-input MFMA kernel "
-                "can be), the bf16 pipe's nominal ceiling for this form is 2500/6 = 416.7 TFLOP/s f32-equivalent "
-                "(frac_of_split_ceiling); on random data the chip holds ~1.8 GHz under this load (mfma_util.json clock_ghz)"
-                if split else "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)")
-        return {"kernel": "%s dW(%dx%d) over %d tokens" % (kern, no, ni, t), "bound": "mfma",
-                "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4),
-                "achieved": ach, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ach / F32_MFMA_PEAK_TF,
-                "frac_of_split_ceiling": (ach / (2500.0 / 6.0)) if split else None, "traffic": pmc_traffic(key, ["wgrad.hip"]),
-                "avg_launch_ms": avg * 1e3,
-                "note": note + "; event-timed launch = split-K kernel + fixed-order second stage; all %d wgrad launches of a "
-                        "step: %.2f ms" % (sum(len(v) for v in by.values()) // steps, total / steps * 1e3)}
+        f32_equiv = flops / avg / 1e12
+        # algorithmic bytes: both operands once + dW; the split-K partials the kernel writes and its second stage reads
+        # again are listed beside it (scratch = S x (out x in + out) floats)
+        alg_bytes = 4.0 * t * (ni + no) + 4.0 * ni * no
+        part_bytes = 2.0 * int(lib.pda_linear_wgrad_scratch_bytes(t, ni, no))
+        traffic = pmc_traffic(key, ["wgrad.hip"])
+        out = {"kernel": "%s dW(%dx%d) over %d tokens" % (kern, no, ni, t), "bound": "mfma",
+               "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4)}
+        if split:
+            work = SPLIT_PRODUCTS * f32_equiv
+            out.update(achieved=work, peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=work / BF16_MFMA_PEAK_TF,
+                       achieved_f32_equiv=f32_equiv, peak_f32_input_mfma=F32_MFMA_PEAK_TF)
+            note = ("three-term bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per f32 product block (f32 accuracy): "
+                    "achieved = 6 x algorithmic flops / time = the bf16 MFMA work really issued, peak = dense bf16 MFMA; "
+                    "achieved_f32_equiv = algorithmic flops / time.  On random data the chip holds ~1.8 GHz under this load "
+                    "(mfma_util.json clock_ghz)")
+        else:
+            out.update(achieved=f32_equiv, peak=F32_MFMA_PEAK_TF, unit="TFLOP/s", frac=f32_equiv / F32_MFMA_PEAK_TF)
+            note = "v_mfma_f32_32x32x2_f32 (f32 in, f32 accumulate)"
+        out.update(traffic=traffic, algorithmic_bytes_per_launch=alg_bytes, split_k_partial_bytes_per_launch=part_bytes,
+                   traffic_over_algorithmic=None if traffic is None else traffic / alg_bytes, avg_launch_ms=avg * 1e3,
+                   note=note + "; event-timed launch = split-K kernel + fixed-order second stage; all %d wgrad launches of a "
+                        "step: %.2f ms" % (sum(len(v) for v in by.values()) // steps, total / steps * 1e3))
+        return out
 
 
 class SamplingGroupingWorkload(KernelTimers):

@@ -17,6 +17,7 @@ from .binding import (  # noqa: F401
     build,
     lib_path,
     opt_n_threads,
+    contract_mode,
     num_threads,
     set_num_threads,
     ball_query_wrapper,

@@ -13,17 +13,18 @@ _i32p = ctypes.POINTER(ctypes.c_int32)
 
 
 def lib_path():
-    return os.path.join(_HERE, "libpda_oracle.so")
+    # PDA_ORACLE_LIB=libpda_oracle_c0.so: the build with the uncontracted distance expression (tests/test_contract0.py)
+    return os.path.join(_HERE, os.environ.get("PDA_ORACLE_LIB") or "libpda_oracle.so")
 
 
 def build(force=False):
-    """Compile the C restatement with gcc (recipe: oracle/Makefile)."""
+    """Compile the C restatement with gcc (recipe: oracle/Makefile): the default build and the uncontracted one."""
     src = os.path.join(_HERE, "pointnet2_oracle.c")
-    so = lib_path()
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libpda_oracle.so"],
-                              stdout=subprocess.DEVNULL)
-    return so
+    for name in ("libpda_oracle.so", "libpda_oracle_c0.so"):
+        so = os.path.join(_HERE, name)
+        if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+            subprocess.check_call(["make", "-C", _HERE, "-B", name], stdout=subprocess.DEVNULL)
+    return lib_path()
 
 
 def _lib():
@@ -53,6 +54,10 @@ def _i(a, shape=None):
 
 def opt_n_threads(n):
     return int(_lib().pda_oracle_opt_n_threads(int(n)))
+
+
+def contract_mode():
+    return int(_lib().pda_oracle_contract_mode())
 
 
 def num_threads():

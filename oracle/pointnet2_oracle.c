@@ -57,6 +57,9 @@ PDA_EXPORT int pda_oracle_opt_n_threads(int work_size) {
     return v;
 }
 
+/* which float expression this build evaluates (1: nvcc's default contraction, 0: uncontracted) */
+PDA_EXPORT int pda_oracle_contract_mode(void) { return PDA_ORACLE_CONTRACT; }
+
 PDA_EXPORT int pda_oracle_num_threads(void) {
 #ifdef _OPENMP
     return omp_get_max_threads();

@@ -862,10 +862,11 @@ def transformer_block(tr, x, pool=False):
 # f32 MFMA kernels instead of the library GEMMs (the weight gradient is csrc/wgrad.hip already); layer 1 gathers its
 # grouped input in the kernel, so the (B, M, ns, 3 + C) tensor only exists in the backward pass.
 SA_MFMA_TRAIN = True
-SA_MFMA_EVENTS = None      # bench: a list collecting (event0, event1, flops) per MFMA launch of the SA group MLPs
+SA_MFMA_EVENTS = None      # bench: a list collecting (event0, event1, flops, pipe) per MFMA launch of the SA group MLPs
 
 
-def _sa_timed(flops, fn):
+def _sa_timed(flops, fn, pipe="f32"):
+    """pipe: "f32" = v_mfma_f32_32x32x2_f32, "bf16x6" = six v_mfma_f32_32x32x16_bf16 per f32 product block (split GEMMs)."""
     ev = SA_MFMA_EVENTS
     if ev is None:
         return fn()
@@ -873,7 +874,7 @@ def _sa_timed(flops, fn):
     e0.record()
     fn()
     e1.record()
-    ev.append((e0, e1, flops))
+    ev.append((e0, e1, flops, pipe))
 
 
 
@@ -883,9 +884,9 @@ def _lin_cols(x2, weight, y, T, k, n_out, transposed):
     if SPLIT_GEMM:
         wf = pointnet2.linear_split_pack(weight, n_out, k, transposed_source=transposed)
         if _rows_in_registers(T, k, n_out):
-            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out))
+            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out), "bf16x6")
         else:
-            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.gemm_split(x2, wf, None, y, T, k, n_out))
+            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.gemm_split(x2, wf, None, y, T, k, n_out), "bf16x6")
     else:
         wf = pointnet2.linear_cols_pack(weight, n_out, k, transposed_source=transposed)
         _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_cols(x2, wf, y, T, k, n_out))

@@ -1,0 +1,57 @@
+"""Parity under EITHER float expression a CUDA build of the reference could evaluate: the reference's
+`a*a + b*b + c*c` becomes fma(c,c,fma(b,b,a*a)) under nvcc's default -fmad=true and stays uncontracted under -fmad=false.
+Library and oracle are built both ways (csrc/Makefile `libpda_pointnet2_c0.so`, oracle/Makefile `libpda_oracle_c0.so`);
+the product is the contracted build.  Here the index-exact FPS / ball-query / 3-NN cases run once more with the
+uncontracted pair, in a child process (the library is chosen at load time)."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_the_two_oracle_builds_evaluate_different_expressions():
+    """The switch is live: on random points the two builds' squared distances differ in the last bit somewhere (and
+    nowhere by more), while on a lattice (exact arithmetic) they agree."""
+    import ctypes
+    sys.path.insert(0, ROOT)
+    import oracle
+    oracle.build()
+    here = os.path.dirname(oracle.lib_path())
+    libs = [ctypes.CDLL(os.path.join(here, n)) for n in ("libpda_oracle.so", "libpda_oracle_c0.so")]
+    assert [l.pda_oracle_contract_mode() for l in libs] == [1, 0]
+    rng = np.random.default_rng(11)
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int32)
+
+    def three_nn(lib, unknown, known):
+        n, m = unknown.shape[1], known.shape[1]
+        d = np.zeros((1, n, 3), np.float32)
+        i = np.zeros((1, n, 3), np.int32)
+        lib.pda_oracle_three_nn(1, n, m, unknown.ctypes.data_as(fp), known.ctypes.data_as(fp), d.ctypes.data_as(fp), i.ctypes.data_as(ip))
+        return d, i
+    u = rng.uniform(-50, 50, (1, 4000, 3)).astype(np.float32)
+    k = rng.uniform(-50, 50, (1, 500, 3)).astype(np.float32)
+    (d1, _), (d0, _) = three_nn(libs[0], u, k), three_nn(libs[1], u, k)
+    assert (d1 != d0).any() and np.allclose(d1, d0, rtol=3e-7, atol=0)
+    ul = rng.integers(-20, 20, (1, 500, 3)).astype(np.float32)
+    kl = rng.integers(-20, 20, (1, 100, 3)).astype(np.float32)
+    (d1, i1), (d0, i0) = three_nn(libs[0], ul, kl), three_nn(libs[1], ul, kl)
+    assert np.array_equal(d1, d0) and np.array_equal(i1, i0)
+
+
+@pytest.mark.gpu
+def test_index_exact_cases_with_the_uncontracted_builds():
+    lib = os.path.join(ROOT, "pdanet_amd", "libpda_pointnet2_c0.so")
+    assert os.path.exists(lib), "build it: make -C pdanet_amd/csrc (or __graft_entry__.build())"
+    env = dict(os.environ, PDA_LIB_PATH=lib, PDA_ORACLE_LIB="libpda_oracle_c0.so", PDA_EXPECT_CONTRACT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(ROOT, "tests", "test_hip_parity.py"), os.path.join(ROOT, "tests", "test_ball_query_cells.py"),
+                        "-k", "fps or ball_query or three_nn or cells or config5"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    m = re.search(r"(\d+) passed", r.stdout)
+    assert m and int(m.group(1)) >= 40, r.stdout[-500:]

@@ -277,3 +277,57 @@ def test_dense_bf16_mode_tracks_fp32():
     for n in big:
         cos = torch.nn.functional.cosine_similarity(ga[n].flatten(), gb[n].flatten(), dim=0).item()
         assert cos > 0.98, (n, cos)
+
+
+# Iteration-0 loss of the HEADLINE configuration (ONCE yaml, B = 2, N = 16384: bench.py's default workload shape);
+# the forward has no float atomics and is deterministic (same argument as PINNED_FIRST_LOSS).
+PINNED_FIRST_LOSS_16K = 138.3255157470703
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_headline_size_model_forward_against_the_oracle(mode, oracle):
+    """Model-level parity at the size the bench is quoted on: the detector's forward on 2 x 16384
+    points in training-mode and in eval-mode BatchNorm.  The D-FPS centres of layer 1 (16384 -> 4096, chain kernel on the
+    side stream) must be the oracle's samples of the same points, the layer-1 neighbour lists around them (both radii,
+    cell list) the oracle's rows, the layer-0 'sampling' the identity; training mode: the first-iteration loss is pinned."""
+    from pdanet_amd import pointnet2_utils as pu
+    B, N = 2, 16384
+    model, opt, sched, bd = _setup("once_pda_ssd.yaml", "once", B=B, N=N)
+    batch = bd()
+    bb = model.backbone_3d
+    if mode == "train":
+        sched.step(0)
+        opt.zero_grad()
+        feats = {}
+        hook = bb.register_forward_hook(lambda m, i, o: feats.update(o))
+        ret, tb, _ = model(batch)
+        hook.remove()
+        loss = float(ret['loss'].detach())
+        assert np.isfinite(loss) and float(tb['center_pos_num']) > 0
+        if PINNED_FIRST_LOSS_16K is not None:
+            assert loss == pytest.approx(PINNED_FIRST_LOSS_16K, rel=1e-4)
+        print("first-iteration loss at 2 x 16384:", repr(loss))
+        out = feats
+    else:
+        model.eval()
+        with torch.no_grad():
+            out = bb(dict(batch))
+        assert torch.isfinite(out['centers_features']).all()
+    xyz = batch['points'][:, 1:4].reshape(B, N, 3).contiguous()
+    enc = out['encoder_xyz']
+    assert torch.equal(enc[1], xyz)                                   # layer 0: N <= npoint, sampling is the identity
+    xyz_np = xyz.cpu().numpy()
+    temp = np.full((B, N), 1e10, np.float32)
+    idx_o = np.zeros((B, 4096), np.int32)
+    oracle.farthest_point_sampling_wrapper(B, N, 4096, xyz_np, temp, idx_o)
+    centres_o = np.stack([xyz_np[i][idx_o[i]] for i in range(B)])
+    assert np.array_equal(centres_o, enc[2].cpu().numpy())             # the model's layer-1 centres == oracle D-FPS picks
+    ids = out['sample_list_id'][1]
+    assert np.array_equal(idx_o, ids.cpu().numpy().astype(np.int32))
+    m1 = bb.SA_modules[1]
+    rows = pu.ball_query_multi(list(m1.radii) if hasattr(m1, "radii") else [g.radius for g in m1.groupers],
+                               list(m1.nsamples), xyz, enc[2].contiguous())
+    for g, got in zip(m1.groupers, rows):
+        exp = np.zeros((B, 4096, g.nsample), np.int32)
+        oracle.ball_query_wrapper(B, N, 4096, g.radius, g.nsample, centres_o, xyz_np, exp)
+        assert np.array_equal(exp, got.cpu().numpy()), g.radius

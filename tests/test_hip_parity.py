@@ -4,6 +4,8 @@ extension module), against the CPU oracle on the same seeded inputs.
 Bar (BASELINE.json north_star): bit-exact for sampled indices and neighbour lists; 1e-4 for
 interpolated features; gradients (float atomics in the reference too) 1e-4 relative.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -11,14 +13,18 @@ torch = pytest.importorskip("torch")
 
 pytestmark = pytest.mark.gpu
 
+# 1: the build with nvcc's default contraction of the distance expression (the product); 0: tests/test_contract0.py
+# re-runs the index-exact cases of this file with the UNcontracted builds of library and oracle
+EXPECT_CONTRACT = int(os.environ.get("PDA_EXPECT_CONTRACT", "1"))
+
 
 @pytest.fixture(scope="module")
-def ext():
+def ext(oracle):
     assert torch.cuda.is_available(), "-m gpu tests need the MI355X"
     from pdanet_amd import pointnet2_batch_cuda
     from pdanet_amd import _lib
     lib = _lib.load()  # raises if libpda_pointnet2.so is missing: no fallback
-    assert lib.pda_fp_contract_mode() == 1
+    assert lib.pda_fp_contract_mode() == EXPECT_CONTRACT and oracle.contract_mode() == EXPECT_CONTRACT
     return pointnet2_batch_cuda
 
 
@@ -408,6 +414,23 @@ def test_config5_sizes_fps_and_ball_query(ext, oracle):
         assert body_ok.all()
         dd = ((xyz[0][rows] - new_xyz[0][:, None]) ** 2).sum(-1)
         assert (dd < r * r * (1 + 1e-5)).all()              # every listed neighbour is inside the ball
+
+
+def test_shipped_once_yaml_input_size_60000(ext, oracle):
+    """The ONCE yaml as shipped feeds 60 000 points (tools/cfgs/once_models/PDA-SSD.yaml:14-17): layer 0
+    then runs D-FPS 60000 -> 16384 (cooperative form, K = 4 workgroups per scene with a ragged last one) and two
+    16384 x 60000 ball queries (cell list).  Indices, final temp and neighbour lists against the oracle."""
+    b, n, m = 2, 60000, 16384
+    xyz = cloud(b, n, seed=60)
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+    assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    new_xyz = np.ascontiguousarray(np.stack([xyz[i][idx_d[i]] for i in range(b)]))
+    from pdanet_amd import pointnet2_utils as pu
+    got = pu.ball_query_multi([0.2, 0.8], [16, 32], dev(xyz), dev(new_xyz))     # the product's dispatch: cell list at this size
+    for (r, ns), g in zip([(0.2, 16), (0.8, 32)], got):
+        exp = np.zeros((b, m, ns), np.int32)
+        oracle.ball_query_wrapper(b, n, m, r, ns, new_xyz, xyz, exp)
+        assert np.array_equal(exp, g.cpu().numpy()), (r, ns)
 
 
 # ---------------------------------------------------------------- Chamfer (SURVEY 8f row f3)

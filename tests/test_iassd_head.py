@@ -225,6 +225,6 @@ def test_box_loss_kernel_nan_targets_follow_the_input():
     p2 = preds.detach().clone().requires_grad_(True)
     w = pos.float() / torch.clamp(pos.sum().float(), min=1.0)
     ref = loss_utils.WeightedSmoothL1Loss(beta=1.0 / 9.0, code_weights=[1.0] * 6).cuda()(p2[None, :, :6], labels[None, :, :6], weights=w[None]).sum()
-    assert float(l_xyz) == pytest.approx(float(ref), rel=2e-5)
+    assert float(l_xyz.detach()) == pytest.approx(float(ref.detach()), rel=2e-5)
     ref.backward()
     assert (preds.grad[:, :6] - p2.grad[:, :6]).abs().max().item() <= 2e-6
