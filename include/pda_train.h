@@ -281,6 +281,33 @@ int pda_head_corner_loss(const float *box_preds, const float *centers, const flo
                          const int64_t *cls_labels, const float *mean_size, int bins, float weight, int64_t n, float *out1,
                          float *grad_box, float *grad_centers, pda_stream_t stream);
 
+/* ---- the NARROW vanilla set-abstraction scale in training form (csrc/sa_train_small.hip; MI355X extension) -------------
+ * QueryAndGroup -> [Conv2d 1x1 (no bias) -> BatchNorm2d (batch statistics) -> ReLU] x 3 -> max over nsample
+ * (pointnet2_modules.py:1657-1670, pointnet2_utils.py:671-704) for chains 3 + c -> c1 -> c2 -> c3 with c <= 5,
+ * c1, c2 in {16, 32} and (nsample, c3) in {(16, 32), (32, 64)}: ONCE / KITTI layer 0.  Forward and backward are families
+ * of recompute passes over the neighbour lists: no (B, M, ns, C) tensor exists in HBM in the forward pass, the backward
+ * pass keeps dz2 (tokens, c2) and dz1 (tokens, c1) only (tokens = b * m * nsample, a multiple of 32).
+ *   fwd: out (b*m, c3) = the pooled activation, zmax = the layer-3 pre-activation at the arg-max, arg = the arg-max slot
+ *        (lowest slot on ties); running statistics of the three BatchNorms updated (entries of running_* may be NULL);
+ *        `workspace` (pda_sa_small_train_workspace_bytes(), 256-byte aligned) receives the packed weights and the batch
+ *        statistics and must reach the backward call unchanged.
+ *   bwd: grad_out (b*m, c3) -> dw1 (c1, 3 + c), dw2 (c2, c1), dw3 (c3, c2), dgamma[l] / dbeta[l] (l = 0..2).  The
+ *        gradient wrt the gathered inputs (xyz, features) is NOT produced: layer 0's inputs are the raw points.
+ * feat_pm is point-major (b, n, c); with c == 1 that is the memory of the reference's (b, 1, n).
+ * Returns PDA_ERR_UNSUPPORTED for any other shape (pda_sa_small_train_supported tells without a call). */
+int64_t pda_sa_small_train_workspace_bytes(void);
+int pda_sa_small_train_supported(int c, int nsample, int c1, int c2, int c3, int64_t tokens);
+int pda_sa_small_train_fwd(const float *xyz, const float *new_xyz, const float *feat_pm, const int32_t *idx,
+                           const float *w1, const float *w2, const float *w3, const float *const *gamma,
+                           const float *const *beta, float *const *running_mean, float *const *running_var,
+                           const float *eps, const float *momentum, void *workspace, float *out, float *zmax,
+                           uint8_t *arg, int b, int n, int m, int c, int nsample, int c1, int c2, int c3,
+                           pda_stream_t stream);
+int pda_sa_small_train_bwd(const float *xyz, const float *new_xyz, const float *feat_pm, const int32_t *idx,
+                           const float *grad_out, const float *zmax, const uint8_t *arg, void *workspace, float *dz2,
+                           float *dz1, float *dw1, float *dw2, float *dw3, float *const *dgamma, float *const *dbeta,
+                           int b, int n, int m, int c, int nsample, int c1, int c2, int c3, pda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

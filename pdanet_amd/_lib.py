@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -111,6 +111,10 @@ SIGNATURES = {
     "pda_boxes_iou_bev": [_vp, _vp, _vp, _i, _i, _vp],
     "pda_nms_mask_words": [_i],
     "pda_nms_bev": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
+    "pda_sa_small_train_workspace_bytes": [],
+    "pda_sa_small_train_supported": [_i, _i, _i, _i, _i, ctypes.c_int64],
+    "pda_sa_small_train_fwd": [_vp] * 7 + [ctypes.POINTER(_vp)] * 4 + [ctypes.POINTER(_f)] * 2 + [_vp] * 4 + [_i] * 8 + [_vp],
+    "pda_sa_small_train_bwd": [_vp] * 13 + [ctypes.POINTER(_vp)] * 2 + [_i] * 8 + [_vp],
     "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
     # include/pda_pointnet2_stack.h
     "pda_stack_ball_query": [_vp, _vp, _vp, _vp, _vp, _i, _i, _f, _i, _vp],
@@ -154,6 +158,7 @@ def load():
     lib.pda_linear_split_packed_bytes.restype = ctypes.c_int64
     lib.pda_colsum_scratch_bytes.restype = ctypes.c_int64
     lib.pda_densitynet_scratch_bytes.restype = ctypes.c_int64
+    lib.pda_sa_small_train_workspace_bytes.restype = ctypes.c_int64
     lib.pda_abi_version.restype = _i
     lib.pda_last_error.restype = ctypes.c_char_p
     lib.pda_fp_contract_mode.restype = _i

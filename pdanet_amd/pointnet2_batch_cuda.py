@@ -646,3 +646,57 @@ def sa_gather_linear(xyz, new_xyz, feats_pm, idx, wf, y, b, n, m, c, nsample, n_
     _call("pda_sa_gather_linear", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32), _chk(feats_pm, "feats_pm", F32),
           _chk(idx, "idx", I32), _chk(wf, "wf", F32), _chk(y, "y", F32), b, n, m, c, nsample, n_out)
     return 1
+
+
+# ---- the narrow vanilla SA scale in training form (csrc/sa_train_small.hip) -------------------------------------------
+@functools.lru_cache(maxsize=None)
+def sa_small_train_workspace_bytes():
+    return int(_lib.load().pda_sa_small_train_workspace_bytes())
+
+
+@functools.lru_cache(maxsize=None)
+def sa_small_train_supported(c, ns, c1, c2, c3, tokens):
+    return bool(_lib.load().pda_sa_small_train_supported(int(c), int(ns), int(c1), int(c2), int(c3), int(tokens)))
+
+
+def _ptr_array(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def sa_small_train_fwd(xyz, new_xyz, feat_pm, idx, weights, gammas, betas, running_means, running_vars, eps, momentum,
+                       workspace, out, zmax, arg, b, n, m, c, ns):
+    """MI355X extension: forward of [group -> (conv1x1 -> BN(batch stats) -> ReLU) x 3 -> max] for the narrow chains of SA
+    layer 0 as recompute passes; out / zmax (b*m, c3) float, arg (b*m, c3) uint8.  weights = (w1, w2, w3) as (c_out, c_in)."""
+    c1, c2, c3 = (int(w.shape[0]) for w in weights)
+    tokens = b * m * ns
+    _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(idx, tokens, "idx")
+    _numel_ok(out, b * m * c3, "out"); _numel_ok(zmax, b * m * c3, "zmax"); _numel_ok(arg, b * m * c3, "arg")
+    _numel_ok(workspace, sa_small_train_workspace_bytes(), "workspace")
+    assert weights[0].shape[1] == 3 + c and weights[1].shape[1] == c1 and weights[2].shape[1] == c2
+    if feat_pm is not None:
+        _numel_ok(feat_pm, b * n * c, "feat_pm")
+    rm = [None if t is None else _chk(t, "running_mean", F32) for t in running_means]
+    rv = [None if t is None else _chk(t, "running_var", F32) for t in running_vars]
+    _buffers_written(rm[0] or rm[1] or rm[2])
+    _call("pda_sa_small_train_fwd", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32),
+          None if feat_pm is None else _chk(feat_pm, "feat_pm", F32), _chk(idx, "idx", I32),
+          _chk(weights[0], "w1", F32), _chk(weights[1], "w2", F32), _chk(weights[2], "w3", F32),
+          _ptr_array([_chk(t, "gamma", F32) for t in gammas]), _ptr_array([_chk(t, "beta", F32) for t in betas]),
+          _ptr_array(rm), _ptr_array(rv), (ctypes.c_float * 3)(*[float(e) for e in eps]),
+          (ctypes.c_float * 3)(*[float(x) for x in momentum]), _chk(workspace, "workspace", torch.uint8),
+          _chk(out, "out", F32), _chk(zmax, "zmax", F32), _chk(arg, "arg", torch.uint8), b, n, m, c, ns, c1, c2, c3)
+    return 1
+
+
+def sa_small_train_bwd(xyz, new_xyz, feat_pm, idx, grad_out, zmax, arg, workspace, dz2, dz1, dws, dgammas, dbetas, b, n, m, c, ns):
+    c1, c2, c3 = (int(w.shape[0]) for w in dws)
+    tokens = b * m * ns
+    _numel_ok(grad_out, b * m * c3, "grad_out"); _numel_ok(dz2, tokens * c2, "dz2"); _numel_ok(dz1, tokens * c1, "dz1")
+    _numel_ok(workspace, sa_small_train_workspace_bytes(), "workspace")
+    _call("pda_sa_small_train_bwd", xyz, _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32),
+          None if feat_pm is None else _chk(feat_pm, "feat_pm", F32), _chk(idx, "idx", I32), _chk(grad_out, "grad_out", F32),
+          _chk(zmax, "zmax", F32), _chk(arg, "arg", torch.uint8), _chk(workspace, "workspace", torch.uint8),
+          _chk(dz2, "dz2", F32), _chk(dz1, "dz1", F32), _chk(dws[0], "dw1", F32), _chk(dws[1], "dw2", F32), _chk(dws[2], "dw3", F32),
+          _ptr_array([_chk(t, "dgamma", F32) for t in dgammas]), _ptr_array([_chk(t, "dbeta", F32) for t in dbetas]),
+          b, n, m, c, ns, c1, c2, c3)
+    return 1

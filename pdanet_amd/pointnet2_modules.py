@@ -411,6 +411,12 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                         new_features_list.append(pooled)
                         continue
                 if use_cl and self.groupers[i].use_xyz:
+                    if (self.training and torch.is_grad_enabled()
+                            and pointnet2_utils.SaSmallChainTrain.supported(xyz, new_xyz, feats_pm, idxs[i], self.mlps[i])):
+                        # narrow chains (layer 0): recompute passes over the neighbour lists, nothing grouped reaches HBM
+                        g = pointnet2_utils.sa_small_chain_train(xyz, new_xyz, feats_pm, idxs[i], self.mlps[i])
+                        new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
+                        continue
                     conv1 = self.mlps[i][0]
                     w1 = conv1.weight.flatten(1)
                     if (torch.is_grad_enabled() and isinstance(conv1, nn.Conv2d) and conv1.bias is None

@@ -981,6 +981,85 @@ class SaGatherLinear(Function):
         return None, g_new, g_feats, None, gw
 
 
+# ---- the narrow vanilla SA scale (layer 0) in training form as recompute passes (csrc/sa_train_small.hip) ------------
+# SA_SMALL_TRAIN: group -> [conv1x1 -> BN(batch statistics) -> ReLU] x 3 -> max of a scale whose widths are <= 64 runs as
+# four forward and four backward passes over the neighbour lists; no (B, M, ns, C) tensor exists in the forward pass.
+SA_SMALL_TRAIN = True
+
+
+class SaSmallChainTrain(Function):
+    """One scale of PointnetSAModuleMSG_WithSampling (pointnet2_modules.py:1657-1670) for the chains of layer 0
+    (4 -> 16 -> 16 -> 32 over 16 neighbours, 4 -> 32 -> 32 -> 64 over 32): out (B, M, c3) = max over nsample of the MLP of
+    [xyz[idx] - new_xyz | feats[idx]].  Gradients: the three convolution weights and the three BatchNorms' affine
+    parameters; the gathered inputs are the raw points (no gradient)."""
+
+    @staticmethod
+    def supported(xyz, new_xyz, feats_pm, idx, mlp):
+        layers = list(mlp)
+        if not (SA_SMALL_TRAIN and len(layers) == 9 and xyz.is_cuda and xyz.dtype == torch.float32 and not DENSE_BF16
+                and not torch.is_autocast_enabled() and not xyz.requires_grad and not new_xyz.requires_grad
+                and (feats_pm is None or (feats_pm.dtype == torch.float32 and not feats_pm.requires_grad))):
+            return False
+        for k in range(3):
+            conv, bn, act = layers[3 * k:3 * k + 3]
+            if not (isinstance(conv, nn.Conv2d) and conv.bias is None and conv.kernel_size == (1, 1) and isinstance(bn, nn.BatchNorm2d)
+                    and isinstance(act, nn.ReLU) and bn.training and bn.affine and bn.momentum is not None
+                    and conv.weight.dtype == torch.float32):
+                return False
+        c = 0 if feats_pm is None else feats_pm.shape[-1]
+        c1, c2, c3 = (layers[3 * k].out_channels for k in range(3))
+        return layers[0].in_channels == 3 + c and pointnet2.sa_small_train_supported(c, idx.shape[2], c1, c2, c3, idx.numel())
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, w1, w2, w3, g1, b1, g2, b2, g3, b3, bns):
+        B, N, _ = xyz.shape
+        M, ns = idx.shape[1], idx.shape[2]
+        c = 0 if feats_pm is None else feats_pm.shape[-1]
+        c3 = w3.shape[0]
+        dev = xyz.device
+        xyz, new_xyz, idx = xyz.contiguous(), new_xyz.contiguous(), idx.contiguous()
+        feats_pm = None if feats_pm is None else feats_pm.contiguous()
+        ws = torch.empty((pointnet2.sa_small_train_workspace_bytes(),), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, M, c3), dtype=torch.float32, device=dev)
+        zmax = torch.empty((B, M, c3), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, M, c3), dtype=torch.uint8, device=dev)
+        track = [bn.track_running_stats for bn in bns]
+        pointnet2.sa_small_train_fwd(xyz, new_xyz, feats_pm, idx, (w1.contiguous(), w2.contiguous(), w3.contiguous()),
+                                     (g1, g2, g3), (b1, b2, b3),
+                                     [bn.running_mean if t else None for bn, t in zip(bns, track)],
+                                     [bn.running_var if t else None for bn, t in zip(bns, track)],
+                                     [bn.eps for bn in bns], [bn.momentum for bn in bns], ws, out, zmax, arg, B, N, M, c, ns)
+        ctx.save_for_backward(xyz, new_xyz, feats_pm, idx, zmax, arg, ws, w1, w2, w3)
+        ctx.dims = (B, N, M, c, ns)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xyz, new_xyz, feats_pm, idx, zmax, arg, ws, w1, w2, w3 = ctx.saved_tensors
+        B, N, M, c, ns = ctx.dims
+        tokens = B * M * ns
+        dev = xyz.device
+        dz2 = torch.empty((tokens, w2.shape[0]), dtype=torch.float32, device=dev)
+        dz1 = torch.empty((tokens, w1.shape[0]), dtype=torch.float32, device=dev)
+        dws = [torch.empty(w.shape, dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
+        dgs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
+        dbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
+        pointnet2.sa_small_train_bwd(xyz, new_xyz, feats_pm, idx, grad_out.contiguous().float(), zmax, arg, ws, dz2, dz1, dws, dgs, dbs,
+                                     B, N, M, c, ns)
+        return (None, None, None, None, dws[0], dws[1], dws[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2], None)
+
+
+def sa_small_chain_train(xyz, new_xyz, feats_pm, idx, mlp):
+    """The scale's [conv -> BN -> ReLU] x 3 nn.Sequential `mlp` applied through SaSmallChainTrain: (B, M, c3)."""
+    layers = list(mlp)
+    convs, bns = [layers[0], layers[3], layers[6]], [layers[1], layers[4], layers[7]]
+    for bn in bns:
+        bump_bn_counter(bn)
+    return SaSmallChainTrain.apply(xyz, new_xyz, feats_pm, idx, convs[0].weight.flatten(1), convs[1].weight.flatten(1),
+                                   convs[2].weight.flatten(1), bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias,
+                                   bns[2].weight, bns[2].bias, bns)
+
+
 # ---- unique-token ("ragged") execution of a PDA scale (csrc/ragged.hip) --------------------------------------------
 # RAGGED_TOKENS: run the encoder of a PDA scale on the distinct (centre, neighbour) tokens only.  RAGGED_MAX_FRACTION:
 # use it when the distinct tokens are at most this share of B*M*nsample (above it the bookkeeping costs more than it saves).

@@ -21,7 +21,7 @@ _ORDER = [
     "test_hip_parity", "test_ball_query_cells", "test_fps_status", "test_points_in_boxes", "test_pointnet2_stack",
     "test_iou3d_nms", "test_contract0",
     "test_golden_composition", "test_iassd_head", "test_optimization",
-    "test_fused_sa_mlp", "test_sa_mlp_train", "test_group_attention", "test_layer_norm", "test_bn_relu",
+    "test_fused_sa_mlp", "test_sa_mlp_train", "test_sa_small_train", "test_group_attention", "test_layer_norm", "test_bn_relu",
     "test_linear_wgrad", "test_gemm_split", "test_densitynet", "test_ragged_tokens",
     "test_parallel_gloo", "test_bench_contract",
     "test_detector_train",
