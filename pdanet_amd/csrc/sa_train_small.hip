@@ -170,12 +170,11 @@ __device__ __forceinline__ void ss_bn_relu(f32x16& z, f32x16& xh, const float* _
     }
 }
 
-// gather the grouped input [xyz[idx] - centre | features[idx]] of token `tok` in B-operand layout (k = 2 t + h)
-__device__ __forceinline__ void ss_gather(const SsParams& p, int64_t tok, int h, float (&x0)[4]) {
+// gather the grouped input [xyz[idx] - centre | features[idx]] of token `tok` (neighbour `id`) in B-operand layout (k = 2 t + h)
+__device__ __forceinline__ void ss_gather(const SsParams& p, int64_t tok, int id, int h, float (&x0)[4]) {
     const int64_t per_scene = (int64_t)p.m * p.ns;
     const int bs = (int)(tok / per_scene);
     const int centre = (int)((tok - bs * per_scene) / p.ns);
-    const int id = p.idx[tok];
     const float* pt = p.xyz + ((size_t)bs * p.n + id) * 3;
     const float* ct = p.new_xyz + ((size_t)bs * p.m + centre) * 3;
     const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];      // pointnet2_utils.py:692
@@ -188,6 +187,31 @@ __device__ __forceinline__ void ss_gather(const SsParams& p, int64_t tok, int h,
         x0[t] = (f && ch < p.c) ? f[ch] : 0.f;
     }
 }
+
+// The walk over a wave's tiles with the gather two deep in flight: a wave runs alone on its SIMD in the heavy passes, so
+// nothing else hides the two dependent loads (neighbour index -> its coordinates) of a tile.  The index of tile i + 2 and
+// the coordinates of tile i + 1 are requested before tile i's MFMA chain; clamped tiles read tile 0 and are never used.
+struct SsWalk {
+    int64_t tile, stride, tiles;
+    int id1, id2;           // neighbour of my token in tile + stride, tile + 2 stride
+    float xn[4];            // gathered input of my token in tile (ready), refilled for tile + stride by advance()
+    __device__ __forceinline__ void start(const SsParams& p, int64_t first, int64_t step, int j, int h) {
+        tile = first; stride = step; tiles = p.tiles;
+        const int id0 = p.idx[(first < tiles ? first : 0) * 32 + j];
+        id1 = p.idx[(first + step < tiles ? first + step : 0) * 32 + j];
+        id2 = p.idx[(first + 2 * step < tiles ? first + 2 * step : 0) * 32 + j];
+        ss_gather(p, (first < tiles ? first : 0) * 32 + j, id0, h, xn);
+    }
+    // x0 = this tile's input; requests the next tile's input and the index two tiles on
+    __device__ __forceinline__ void fetch(const SsParams& p, int j, int h, float (&x0)[4]) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) x0[t] = xn[t];
+        const int64_t n1 = tile + stride < tiles ? tile + stride : 0, n3 = tile + 3 * stride < tiles ? tile + 3 * stride : 0;
+        ss_gather(p, n1 * 32 + j, id1, h, xn);
+        id1 = id2;
+        id2 = p.idx[n3 * 32 + j];
+    }
+};
 
 __device__ __forceinline__ float ss_half_sum(float v) {     // sum over the 32 lanes of my half (every lane gets it)
 #pragma unroll
@@ -289,9 +313,12 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_fwd_kernel(const SsParams p)
     float emu = 0.f, eis = 0.f, ega = 0.f, ebe = 0.f;
     if (STAGE == 4) { emu = st3[ech]; eis = st3[32 * R3 + ech]; ega = st3[64 * R3 + ech]; ebe = st3[96 * R3 + ech]; }
 
-    for (int64_t tile = (int64_t)blockIdx.x * SS_WAVES + w; tile < p.tiles; tile += (int64_t)gridDim.x * SS_WAVES) {
+    SsWalk walk;
+    walk.start(p, (int64_t)blockIdx.x * SS_WAVES + w, (int64_t)gridDim.x * SS_WAVES, j, h);
+    for (; walk.tile < p.tiles; walk.tile += walk.stride) {
+        const int64_t tile = walk.tile;
         float x0[4];
-        ss_gather(p, tile * 32 + j, h, x0);
+        walk.fetch(p, j, h, x0);
         f32x16 a1[1], a2[1], a3[R3], dummy;
         ss_mm<4, 1>(a1, SsX0{x0}, w1);
         if (STAGE == 1) {
@@ -407,10 +434,31 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
     const int cdn = STAGE == 3 ? p.c2 : p.c1;         // channels of the gradient tensor this pass writes (STAGE >= 2)
     const int cup = STAGE == 2 ? p.c2 : p.c1;         // ... and of the one it reads (STAGE <= 2)
 
-    for (int64_t tile = (int64_t)blockIdx.x * SS_WAVES + w; tile < p.tiles; tile += (int64_t)gridDim.x * SS_WAVES) {
+    SsWalk walk;
+    walk.start(p, (int64_t)blockIdx.x * SS_WAVES + w, (int64_t)gridDim.x * SS_WAVES, j, h);
+    for (; walk.tile < p.tiles; walk.tile += walk.stride) {
+        const int64_t tile = walk.tile;
         const int64_t tok = tile * 32 + j;
         float x0[4];
-        ss_gather(p, tok, h, x0);
+        walk.fetch(p, j, h, x0);
+        // the gradient this pass starts from, requested before the recompute chain
+        const int64_t g = NS == 32 ? tile : tile * 2 + (j >> 4);
+        float4 gin[STAGE == 3 ? R3 : 1][4];
+        uchar4 ain[STAGE == 3 ? R3 : 1][4];
+        if constexpr (STAGE == 3) {
+#pragma unroll
+            for (int rb = 0; rb < R3; ++rb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    gin[rb][q] = *reinterpret_cast<const float4*>(p.gout + g * p.c3 + rb * 32 + 8 * q + 4 * h);
+                    ain[rb][q] = *reinterpret_cast<const uchar4*>(p.arg_in + g * p.c3 + rb * 32 + 8 * q + 4 * h);
+                }
+        } else {
+            const float* row = p.dz_in + tok * cup;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                gin[0][q] = 8 * q + 4 * h < cup ? *reinterpret_cast<const float4*>(row + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
+        }
         f32x16 a1[1], xh1, a2[1], xh2, a3[R3], d[1];
         ss_mm<4, 1>(a1, SsX0{x0}, w1);
         ss_bn_relu<true>(a1[0], xh1, st1, 32, 0, h);                  // a1 = y1
@@ -421,7 +469,6 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
         if constexpr (STAGE == 3) {
             ss_mm<16, R3>(a3, SsAcc<1>{a2}, w3);
             // dz3 = gamma3 invstd3 (dyh - mean(dyh) - xh3 mean(dyh xh3)), dyh = the pooled gradient at the arg-max slot
-            const int64_t g = NS == 32 ? tile : tile * 2 + (j >> 4);
             const int slot = j & (NS - 1);
 #pragma unroll
             for (int rb = 0; rb < R3; ++rb)
@@ -430,8 +477,8 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
                     const SsChan c = ss_chan(st3, 32 * R3, rb, q, h);
                     const float4 m1 = *reinterpret_cast<const float4*>(st3 + 4 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
                     const float4 m2 = *reinterpret_cast<const float4*>(st3 + 5 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
-                    const float4 go = *reinterpret_cast<const float4*>(p.gout + g * p.c3 + rb * 32 + 8 * q + 4 * h);
-                    const uchar4 ar = *reinterpret_cast<const uchar4*>(p.arg_in + g * p.c3 + rb * 32 + 8 * q + 4 * h);
+                    const float4 go = gin[rb][q];
+                    const uchar4 ar = ain[rb][q];
                     const int av[4] = {ar.x, ar.y, ar.z, ar.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -449,13 +496,11 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
         } else {
             // the gradient this pass starts from: dz' (tokens, cup), already masked by its ReLU
             f32x16 dzp;
-            const float* row = p.dz_in + tok * cup;
             const float* stl = STAGE == 2 ? st2 : st1;
             const f32x16& xh = STAGE == 2 ? xh2 : xh1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const bool ok = 8 * q + 4 * h < cup;
-                const float4 v = ok ? *reinterpret_cast<const float4*>(row + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
+                const float4 v = gin[0][q];
                 const SsChan c = ss_chan(stl, 32, 0, q, h);
                 const float4 m1 = *reinterpret_cast<const float4*>(stl + 4 * 32 + 8 * q + 4 * h);
                 const float4 m2 = *reinterpret_cast<const float4*>(stl + 5 * 32 + 8 * q + 4 * h);
@@ -559,17 +604,28 @@ __global__ __launch_bounds__(1024) void ss_finalize_bwd_kernel(const double* __r
         if (ch < c) { dbeta[ch] = (float)s1; dgamma[ch] = (float)s2; }
         return;
     }
-    const int e = (blockIdx.x - 1) * 1024 + threadIdx.x;
-    if (dw == nullptr || e >= dw_rows * dw_cols) return;
-    const int row = e / dw_cols, col = e % dw_cols;
+    // 64 elements x 16 slices of the workgroup partials per block; slices summed in fixed order
+    __shared__ double red[16][64];
+    const int el = threadIdx.x & 63, part = threadIdx.x >> 6;
+    const int e = (blockIdx.x - 1) * 64 + el;
+    const bool ok = dw != nullptr && e < dw_rows * dw_cols;
+    const int row = ok ? e / dw_cols : 0, col = ok ? e % dw_cols : 0;
     double a = 0.0;
-    for (int k = 0; k < dw_blocks; ++k) a += (double)dw_partial[(size_t)k * SS_DW + row * 32 + col];
-    dw[e] = (float)a;
+    if (ok)
+        for (int k = part; k < dw_blocks; k += 16) a += (double)dw_partial[(size_t)k * SS_DW + row * 32 + col];
+    red[part][el] = a;
+    __syncthreads();
+    if (part == 0 && ok) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][el];
+        dw[e] = (float)t;
+    }
 }
 
-static int ss_blocks(int64_t tiles) {
+static int ss_blocks(int64_t tiles, int cap = SS_MAX_BLOCKS) {
     const int64_t want = divup64(tiles, SS_WAVES);
-    return (int)(want < SS_MAX_BLOCKS ? want : SS_MAX_BLOCKS);
+    return (int)(want < cap ? want : cap);
 }
 
 template <int R3, int NS>
@@ -673,7 +729,7 @@ PDA_API int pda_sa_small_train_bwd(const float* xyz, const float* new_xyz, const
     p.n = n; p.m = m; p.c = c; p.ns = ns; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     const int64_t tokens = (int64_t)b * m * ns, groups = (int64_t)b * m;
     p.tiles = tokens / 32;
-    const int blocks = ss_blocks(p.tiles);
+    const int blocks = ss_blocks(p.tiles, 256);      // the heavy passes hold one wave per SIMD: one workgroup per CU
     const int R3 = c3 / 32;
     // E0: BatchNorm-3 backward sums from the pooled side
     const int pb = (int)(divup64(groups, 256 / (c3 / 4)) < 256 ? divup64(groups, 256 / (c3 / 4)) : 256);
@@ -684,17 +740,17 @@ PDA_API int pda_sa_small_train_bwd(const float* xyz, const float* new_xyz, const
     // B3: dW3, dz2', BatchNorm-2 sums
     p.dz_out = dz2;
     if (R3 == 1) ss_launch_bwd<1, 16>(3, p, blocks, s); else ss_launch_bwd<2, 32>(3, p, blocks, s);
-    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c3 * c2, 1024)), dim3(1024), 0, s, (const double*)p.partial, blocks, c2, 32, tokens,
+    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c3 * c2, 64)), dim3(1024), 0, s, (const double*)p.partial, blocks, c2, 32, tokens,
                        state + ss_state_base(2), dgamma[1], dbeta[1], (const float*)p.dw_partial, blocks, c3, c2, dw3);
     // B2: dW2, dz1', BatchNorm-1 sums
     p.dz_in = dz2; p.dz_out = dz1;
     if (R3 == 1) ss_launch_bwd<1, 16>(2, p, blocks, s); else ss_launch_bwd<2, 32>(2, p, blocks, s);
-    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c2 * c1, 1024)), dim3(1024), 0, s, (const double*)p.partial, blocks, c1, 32, tokens,
+    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c2 * c1, 64)), dim3(1024), 0, s, (const double*)p.partial, blocks, c1, 32, tokens,
                        state + ss_state_base(1), dgamma[0], dbeta[0], (const float*)p.dw_partial, blocks, c2, c1, dw2);
     // B1: dW1
     p.dz_in = dz1; p.dz_out = nullptr;
     if (R3 == 1) ss_launch_bwd<1, 16>(1, p, blocks, s); else ss_launch_bwd<2, 32>(1, p, blocks, s);
-    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c1 * (3 + c), 1024)), dim3(1024), 0, s, (const double*)nullptr, 0, 0, 0, tokens,
+    hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c1 * (3 + c), 64)), dim3(1024), 0, s, (const double*)nullptr, 0, 0, 0, tokens,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)p.dw_partial, blocks, c1, 3 + c, dw1);
     return check_launch("pda_sa_small_train_bwd");
 }

@@ -22,7 +22,7 @@ def _setup(cfg, dataset, B=2, N=4096):
 # Iteration-0 loss of the setup above, identical to the last bit on four different MI355X boxes in rounds 1-2
 # (GPUTEST_r01.json, gpurun_out/hang.log, gpurun_out/r02_trace.log): the forward pass has no float atomics and
 # is deterministic.  rel=1e-4 leaves room for a different library-GEMM heuristic on another ROCm build.
-PINNED_FIRST_LOSS = {"once": 29.138835906982422, "kitti": 161.17782592773438}
+PINNED_FIRST_LOSS = {"once": 29.190820693969727, "kitti": 161.17782592773438}
 CASES = [("once_pda_ssd.yaml", "once"), ("kitti_pda_ssd.yaml", "kitti")]
 
 
