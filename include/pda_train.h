@@ -308,6 +308,16 @@ int pda_sa_small_train_bwd(const float *xyz, const float *new_xyz, const float *
                            float *dz1, float *dw1, float *dw2, float *dw3, float *const *dgamma, float *const *dbeta,
                            int b, int n, int m, int c, int nsample, int c1, int c2, int c3, pda_stream_t stream);
 
+/* ---- the coordinate columns of a vanilla SA scale's first layer, backward (csrc/sa_xyz_grad.hip; MI355X extension) ----
+ * z1 = [xyz[idx] - new_xyz | features[idx]] W1^T, W1 (c1, ldw >= 3 + C).  From grad_z1 (b*m*nsample, c1):
+ * dw[o][0:3] (row stride lddw) = sum over tokens of grad_z1[t][o] * (xyz[idx[t]] - new_xyz[centre(t)]) and, when
+ * grad_new_xyz (b, m, 3) is not NULL, grad_new_xyz[centre] = -(sum over the centre's samples of grad_z1) W1[:, 0:3].
+ * One pass over grad_z1; the feature columns go through pda_linear_wgrad / pda_gemm_split. */
+int64_t pda_sa_xyz_grad_scratch_bytes(int c1);
+int pda_sa_xyz_grad(const float *grad_z1, const float *xyz, const float *new_xyz, const int32_t *idx, const float *w, int ldw,
+                    float *dw, int lddw, float *grad_new_xyz, void *scratch, int b, int n, int m, int nsample, int c1,
+                    pda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,126 @@
+// sa_xyz_grad.hip -- the COORDINATE columns of the first layer of a vanilla set-abstraction scale in the backward pass
+// (include/pda_train.h).  z1 = [xyz[idx] - new_xyz | features[idx]] W1^T with W1 (c1, 3 + C) (QueryAndGroup + the first
+// 1x1 convolution, pointnet2_utils.py:671-704 + pointnet2_modules.py:1657).  Its backward splits by column block:
+//   * the C feature columns are a plain (tokens x C) problem: weight gradient on csrc/wgrad.hip, input gradient on
+//     csrc/gemm_split.hip, both at full matrix-core width (C = 256);
+//   * the 3 coordinate columns made the whole thing a 259-wide problem that went to the library.  Here they are one
+//     streaming pass over grad_z1 (thread = output channel, tokens in order): dW1[:, 0:3] += g (x) (xyz[idx] - centre)
+//     and, per centre, grad_new_xyz = -(sum over its samples of g) W1[:, 0:3] -- the centre enters every sample with -1.
+// The pass reads grad_z1 once (tokens * c1 * 4 bytes) and nothing else of size.
+#include "pda_common.h"
+
+namespace pda {
+
+constexpr int XG_BLOCKS = 512;
+constexpr int XG_THREADS = 256;
+constexpr int XG_MAXC = 4;      // channels per thread: c1 <= 1024
+
+template <int CPT>
+__global__ __launch_bounds__(XG_THREADS) void sa_xyz_grad_kernel(const float* __restrict__ g, const float* __restrict__ xyz,
+                                                                 const float* __restrict__ new_xyz, const int32_t* __restrict__ idx,
+                                                                 const float* __restrict__ w, int ldw, float* __restrict__ partial,
+                                                                 float* __restrict__ grad_new, int n, int m, int ns, int c1, int64_t groups) {
+    __shared__ float red[XG_THREADS / 64][3];
+    const int tid = threadIdx.x;
+    float accw[CPT][3], wx[CPT][3];
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int o = tid + q * XG_THREADS;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { accw[q][d] = 0.f; wx[q][d] = o < c1 ? w[(size_t)o * ldw + d] : 0.f; }
+    }
+    for (int64_t grp = blockIdx.x; grp < groups; grp += gridDim.x) {
+        const int bs = (int)(grp / m);
+        const float* ct = new_xyz + grp * 3;
+        const float cx = ct[0], cy = ct[1], cz = ct[2];
+        const float* pts = xyz + (size_t)bs * n * 3;
+        const int32_t* ids = idx + grp * ns;
+        const float* grow = g + grp * ns * (int64_t)c1;
+        float gs[CPT];
+#pragma unroll
+        for (int q = 0; q < CPT; ++q) gs[q] = 0.f;
+        for (int s0 = 0; s0 < ns; s0 += 8) {
+            float gv[8][CPT], dx[8], dy[8], dz[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int s = s0 + u < ns ? s0 + u : ns - 1;
+                const float* pt = pts + (size_t)ids[s] * 3;
+                dx[u] = pt[0] - cx; dy[u] = pt[1] - cy; dz[u] = pt[2] - cz;          // pointnet2_utils.py:692
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    const int o = tid + q * XG_THREADS;
+                    gv[u][q] = (s0 + u < ns && o < c1) ? grow[(int64_t)s * c1 + o] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int q = 0; q < CPT; ++q) {
+                    accw[q][0] = __builtin_fmaf(gv[u][q], dx[u], accw[q][0]);
+                    accw[q][1] = __builtin_fmaf(gv[u][q], dy[u], accw[q][1]);
+                    accw[q][2] = __builtin_fmaf(gv[u][q], dz[u], accw[q][2]);
+                    gs[q] += gv[u][q];
+                }
+        }
+        if (grad_new) {
+            float v[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < CPT; ++q)
+#pragma unroll
+                for (int d = 0; d < 3; ++d) v[d] = __builtin_fmaf(gs[q], wx[q][d], v[d]);
+#pragma unroll
+            for (int d = 0; d < 3; ++d) {
+#pragma unroll
+                for (int o = 32; o >= 1; o >>= 1) v[d] += __shfl_xor(v[d], o);
+            }
+            __syncthreads();                     // the previous group's result has been read
+            if (lane_id() == 0) { red[wave_id()][0] = v[0]; red[wave_id()][1] = v[1]; red[wave_id()][2] = v[2]; }
+            __syncthreads();
+            if (tid < 3) grad_new[grp * 3 + tid] = -((red[0][tid] + red[1][tid]) + (red[2][tid] + red[3][tid]));
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < CPT; ++q) {
+        const int o = tid + q * XG_THREADS;
+        if (o < c1) {
+            float* p = partial + ((size_t)blockIdx.x * c1 + o) * 3;
+            p[0] = accw[q][0]; p[1] = accw[q][1]; p[2] = accw[q][2];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void sa_xyz_grad_reduce_kernel(const float* __restrict__ partial, int nblocks, int c1, float* __restrict__ dw, int lddw) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= c1 * 3) return;
+    double a = 0.0;
+    for (int k = 0; k < nblocks; ++k) a += (double)partial[(size_t)k * c1 * 3 + e];
+    dw[(size_t)(e / 3) * lddw + e % 3] = (float)a;
+}
+
+}  // namespace pda
+
+PDA_API int64_t pda_sa_xyz_grad_scratch_bytes(int c1) { return c1 > 0 ? (int64_t)pda::XG_BLOCKS * c1 * 3 * sizeof(float) : 0; }
+
+PDA_API int pda_sa_xyz_grad(const float* grad_z1, const float* xyz, const float* new_xyz, const int32_t* idx, const float* w, int ldw,
+                            float* dw, int lddw, float* grad_new_xyz, void* scratch, int b, int n, int m, int ns, int c1,
+                            pda_stream_t stream) {
+    using namespace pda;
+    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && ns >= 1 && c1 >= 1 && ldw >= 3 && lddw >= 3, "pda_sa_xyz_grad: bad size");
+    const int64_t groups = (int64_t)b * m;
+    if (groups == 0) return PDA_OK;
+    PDA_REQUIRE(grad_z1 && xyz && new_xyz && idx && w && dw && scratch, "pda_sa_xyz_grad: null pointer");
+    if (c1 > XG_THREADS * XG_MAXC) {
+        set_error("pda_sa_xyz_grad: c1 = %d > %d", c1, XG_THREADS * XG_MAXC);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    const hipStream_t s = (hipStream_t)stream;
+    const int blocks = (int)(groups < XG_BLOCKS ? groups : XG_BLOCKS);
+    float* partial = (float*)scratch;
+    const int cpt = divup(c1, XG_THREADS);
+#define PDA_XG(CPT) hipLaunchKernelGGL((sa_xyz_grad_kernel<CPT>), dim3(blocks), dim3(XG_THREADS), 0, s, grad_z1, xyz, new_xyz, idx, w, ldw, \
+                                       partial, grad_new_xyz, n, m, ns, c1, groups)
+    if (cpt == 1) PDA_XG(1); else if (cpt == 2) PDA_XG(2); else PDA_XG(4);
+#undef PDA_XG
+    hipLaunchKernelGGL(sa_xyz_grad_reduce_kernel, dim3(divup(c1 * 3, 256)), dim3(256), 0, s, (const float*)partial, blocks, c1, dw, lddw);
+    return check_launch("pda_sa_xyz_grad");
+}

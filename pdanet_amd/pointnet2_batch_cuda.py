@@ -700,3 +700,22 @@ def sa_small_train_bwd(xyz, new_xyz, feat_pm, idx, grad_out, zmax, arg, workspac
           _ptr_array([_chk(t, "dgamma", F32) for t in dgammas]), _ptr_array([_chk(t, "dbeta", F32) for t in dbetas]),
           b, n, m, c, ns, c1, c2, c3)
     return 1
+
+
+@functools.lru_cache(maxsize=None)
+def sa_xyz_grad_scratch_bytes(c1):
+    return int(_lib.load().pda_sa_xyz_grad_scratch_bytes(int(c1)))
+
+
+def sa_xyz_grad(grad_z1, xyz, new_xyz, idx, w, dw, grad_new_xyz, b, n, m, ns, c1):
+    """MI355X extension: the 3 coordinate columns of a vanilla SA scale's first layer in the backward pass
+    (csrc/sa_xyz_grad.hip): dw[:, 0:3] and grad_new_xyz (b, m, 3) from grad_z1 (b*m*ns, c1); w / dw are (c1, 3 + C)."""
+    _numel_ok(grad_z1, b * m * ns * c1, "grad_z1"); _numel_ok(idx, b * m * ns, "idx")
+    _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz")
+    assert w.shape[0] == c1 and dw.shape == w.shape and w.shape[1] >= 3
+    scratch = torch.empty((sa_xyz_grad_scratch_bytes(c1),), dtype=torch.uint8, device=xyz.device)
+    _call("pda_sa_xyz_grad", xyz, _chk(grad_z1, "grad_z1", F32), _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32),
+          _chk(idx, "idx", I32), _chk(w, "w", F32), int(w.shape[1]), _chk(dw, "dw", F32), int(dw.shape[1]),
+          None if grad_new_xyz is None else _chk(grad_new_xyz, "grad_new_xyz", F32), _chk(scratch, "scratch", torch.uint8),
+          b, n, m, ns, c1)
+    return 1

@@ -960,24 +960,31 @@ class SaGatherLinear(Function):
 
     @staticmethod
     def backward(ctx, grad_out):
+        """By column block of W1 = [W_xyz (n_out, 3) | W_f (n_out, C)]: the feature block is a plain (tokens x C) problem --
+        weight gradient on csrc/wgrad.hip from the re-gathered neighbour rows, input gradient on csrc/gemm_split.hip, then the
+        scatter-add onto the points; the coordinate block (weight gradient and the centres' gradient) is one streaming
+        pass over grad_out (csrc/sa_xyz_grad.hip).  No 259-column tensor is built and nothing goes to the library."""
         xyz, new_xyz, feats_pm, idx, weight = ctx.saved_tensors
         B, M, ns = idx.shape
-        n_out = weight.shape[0]
+        n_out, C, N = weight.shape[0], feats_pm.shape[-1], xyz.shape[1]
         g2 = grad_out.contiguous().view(-1, n_out)
+        T = g2.shape[0]
         g_new = g_feats = gw = None
         with torch.no_grad():
+            if ctx.needs_input_grad[4] or ctx.needs_input_grad[1]:
+                gw = torch.empty_like(weight)
+                g_new = torch.empty_like(new_xyz) if ctx.needs_input_grad[1] else None
+                pointnet2.sa_xyz_grad(g2, xyz, new_xyz, idx, weight.contiguous(), gw, g_new, B, N, M, ns, n_out)
             if ctx.needs_input_grad[4]:
-                x0 = torch.cat([group_rows(xyz, idx) - new_xyz.unsqueeze(2), group_rows(feats_pm, idx)], dim=-1).view(-1, weight.shape[1])
-                gw = _wgrad(x0, g2, weight, False)[0]
-                del x0
-            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                gx0 = _gemm_nn(g2, weight).view(B, M, ns, -1)
-                if ctx.needs_input_grad[1]:
-                    g_new = -gx0[..., :3].sum(dim=2)
-                if ctx.needs_input_grad[2]:
-                    g_feats = torch.zeros_like(feats_pm)
-                    gf = gx0[..., 3:].contiguous()
-                    pointnet2.group_rows_grad(B, feats_pm.shape[1], feats_pm.shape[2], M * ns, gf, idx, g_feats)
+                gf_in = group_rows(feats_pm, idx).view(T, C)            # the grouped features exist for this product only
+                gw[:, 3:] = _wgrad(gf_in, g2, torch.empty((n_out, C), dtype=weight.dtype, device=weight.device), False)[0]
+                del gf_in
+            else:
+                gw = None
+            if ctx.needs_input_grad[2]:
+                gxf = _gemm_nn(g2, weight[:, 3:].contiguous())           # (T, C)
+                g_feats = torch.zeros_like(feats_pm)
+                pointnet2.group_rows_grad(B, feats_pm.shape[1], C, M * ns, gxf, idx, g_feats)
         return None, g_new, g_feats, None, gw
 
 

@@ -99,3 +99,26 @@ def test_sa_layer_training_mfma_path_equals_library_path():
         assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-2 * float(b[3][k].abs().max()) + 1e-3 * gmax, k
     for k in b[4]:
         assert torch.allclose(a[4][k], b[4][k], rtol=1e-4, atol=1e-5), k
+
+
+@pytest.mark.parametrize("b,n,m,ns,c1", [(2, 512, 96, 16, 256), (1, 300, 50, 13, 128), (2, 256, 33, 64, 512)])
+def test_sa_xyz_grad_kernel_against_fp64(b, n, m, ns, c1):
+    """csrc/sa_xyz_grad.hip: the coordinate columns of the first SA layer's backward (weight gradient columns 0:3 and the
+    centres' gradient) against the same sums in torch fp64."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    g = torch.Generator().manual_seed(b * 100 + ns)
+    xyz = (torch.rand(b, n, 3, generator=g) * 10).cuda()
+    new_xyz = (torch.rand(b, m, 3, generator=g) * 10).cuda()
+    idx = torch.randint(0, n, (b, m, ns), generator=g, dtype=torch.int32).cuda()
+    gz = torch.randn(b * m * ns, c1, generator=g).cuda()
+    w = torch.randn(c1, 3 + 7, generator=g).cuda()
+    dw = torch.full_like(w, 7.0)
+    gnew = torch.empty(b, m, 3, device="cuda")
+    ext.sa_xyz_grad(gz, xyz, new_xyz, idx, w, dw, gnew, b, n, m, ns, c1)
+    gx = torch.stack([xyz[i][idx[i].long()] for i in range(b)]).double() - new_xyz.double().unsqueeze(2)      # (b, m, ns, 3)
+    gz64 = gz.double().view(b, m, ns, c1)
+    want_dw = torch.einsum("bmso,bmsd->od", gz64, gx)
+    want_new = -(gz64.sum(dim=2) @ w[:, :3].double())
+    assert (dw[:, :3].double() - want_dw).abs().max().item() <= 2e-5 * want_dw.abs().max().item()
+    assert (dw[:, 3:] == 7.0).all()                       # the feature columns are not this kernel's
+    assert (gnew.double() - want_new).abs().max().item() <= 2e-5 * want_new.abs().max().item()
