@@ -476,12 +476,19 @@ class BackboneInferWorkload(BackboneWorkload):
         fused_ops.enable_fused(self.model)
         self.ddp = None
         self.sa_events = []
+        self._primed = False
 
     def step(self):
+        """One forward.  The NEXT batch is resident (synthetic data; a serving queue in a real run), so its coordinate-only
+        front (D-FPS 16384 -> 4096: 2.6 ms on 2 CUs, layer-1 ball queries, token plans) is started on the side stream BEFORE
+        this batch's forward and runs under all of it; every step still does that work exactly once."""
         self.fused_ops.PROFILE = self.sa_events if self.record else None
         with torch.no_grad():
+            if not self._primed:
+                self._prefetch_next()        # this batch's own front (first step only)
+                self._primed = True
+            self._prefetch_next()            # the next batch's front
             bd = self.model({'batch_size': self.B, 'points': self.points, 'inputs_resident': True})
-            self._prefetch_next()
         self.fused_ops.PROFILE = None
         return bd['centers_features']
 

@@ -79,7 +79,7 @@ class IASSD_Backbone(nn.Module):
         # D-FPS layers are sampled on a side stream while the main stream runs layer 0.
         self.prefetch_sampling = True
         self._side_stream = None
-        self._prefetched = None
+        self._prefetched = []          # FIFO of (key, presampled) started by prefetch(), oldest first, at most two
 
     def _presample(self, xyz, points=None, batch_size=None, limit=None):
         """Sampling of the leading layers that need only coordinates (identity / D-FPS, chained
@@ -150,12 +150,16 @@ class IASSD_Backbone(nn.Module):
         their ball queries and unique-token plans.  `points` must be the tensor the next forward is called with, already
         resident in HBM and not modified in between.  In a training loop this is called right after the forward of step i
         with the batch of step i+1 (a data loader's prefetch): the 3.7 ms D-FPS latency chain and the plan's host read then
-        sit under step i's backward instead of in front of layer 1."""
+        sit under step i's backward instead of in front of layer 1.  Two batches may be in flight: a serving loop whose next
+        batch is resident calls this BEFORE the forward of the current one, so the next batch's sampling runs under the whole
+        current forward (a forward consumes the oldest entry that matches its batch; entries of other batches are dropped)."""
         if not (self.prefetch_sampling and points.is_cuda):
             return
         xyz = points[:, 1:4].reshape(batch_size, -1, 3)
-        self._prefetched = ((points.data_ptr(), tuple(points.shape), points._version, batch_size),
-                            self._presample(xyz, points, batch_size))
+        if len(self._prefetched) >= 2:
+            self._prefetched.pop(0)
+        self._prefetched.append(((points.data_ptr(), tuple(points.shape), points._version, batch_size),
+                                 self._presample(xyz, points, batch_size)))
 
     @staticmethod
     def break_up_pc(pc):
@@ -204,8 +208,12 @@ class IASSD_Backbone(nn.Module):
                   bidx=batch_idx.view(batch_size, -1), li_cls_pred=None, presampled={})
         resident = bool(batch_dict.get('inputs_resident', False))
         if self.prefetch_sampling:
-            stash, self._prefetched = self._prefetched, None
-            if stash is not None and stash[0] == (points.data_ptr(), tuple(points.shape), points._version, batch_size):
+            key = (points.data_ptr(), tuple(points.shape), points._version, batch_size)
+            stash = None
+            while self._prefetched and stash is None:
+                cand = self._prefetched.pop(0)
+                stash = cand if cand[0] == key else None    # an entry made for another batch is stale: dropped
+            if stash is not None:
                 st['presampled'] = stash[1]                 # started by prefetch() during the previous iteration
             else:
                 st['presampled'] = self._presample(xyz, points if resident else None, batch_size, limit=first_graphed)

@@ -34,9 +34,13 @@ namespace pda {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int SS_WAVES = 4;
+constexpr int SS_WAVES = 8;                         // waves per workgroup: two per SIMD -- one wave's VALU / memory work runs under the other's MFMA chain
+constexpr int SS_WAVES_HEAVY = 4;                   // the one pass whose working set needs more than 256 registers (B3 at c3 = 64)
 constexpr int SS_LD = 33;                           // row stride (floats) of the transposed tiles
 constexpr int SS_LDS_WAVE = 96 * SS_LD;             // per wave: a 64-row block + a 32-row block
+constexpr int SS_LDS_WPACK = 6400;                   // LDS (floats): [packed weights | state | per-wave tiles]
+constexpr int SS_LDS_STATE = 768;
+__host__ __device__ constexpr int ss_lds_floats(int waves) { return SS_LDS_WPACK + SS_LDS_STATE + waves * SS_LDS_WAVE; }
 constexpr int SS_MAX_BLOCKS = 512;                  // workgroups per pass = per-pass partials
 constexpr int SS_PART = 128;                        // doubles per workgroup partial: [2][64]
 constexpr int SS_DW = 2048;                         // floats per workgroup weight-gradient partial: [64][32]
@@ -101,14 +105,11 @@ __global__ void ss_pack_kernel(const float* __restrict__ w1, const float* __rest
 
 // ---- register-resident weight fragments and the chain's GEMM ---------------------------------------------------------
 template <int KS, int R>
-struct SsFrag {
-    float4 f[KS / 4][R];
-    __device__ __forceinline__ void load(const float* __restrict__ wf, int lane) {
-#pragma unroll
-        for (int tq = 0; tq < KS / 4; ++tq)
-#pragma unroll
-            for (int r = 0; r < R; ++r) f[tq][r] = *reinterpret_cast<const float4*>(wf + ((size_t)(tq * R + r) * 64 + lane) * 4);
-    }
+struct SsFrag {      // fragments of one packed matrix in LDS (shared by the workgroup's waves): one ds_read_b128 per 4 MFMAs
+    const float* wf;
+    int lane;
+    __device__ __forceinline__ void load(const float* lds_wf, int l) { wf = lds_wf; lane = l; }
+    __device__ __forceinline__ float4 f(int tq, int r) const { return *reinterpret_cast<const float4*>(wf + ((tq * R + r) * 64 + lane) * 4); }
 };
 
 // acc[r] = W[row block r] x Hin over KS k-steps; hin(t) = the lane's B operand of k-step t (static index)
@@ -125,7 +126,7 @@ __device__ __forceinline__ void ss_mm(f32x16 (&acc)[R], const HinT& hin, const S
             const float b = hin(tq * 4 + e);
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                const float4 a4 = w.f[tq][r];
+                const float4 a4 = w.f(tq, r);
                 const float av = e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w));
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
             }
@@ -220,11 +221,11 @@ __device__ __forceinline__ float ss_half_sum(float v) {     // sum over the 32 l
 }
 
 // per-lane (sum, weighted sum) registers of NB row blocks -> the workgroup's partial [2][64] (doubles, fixed order)
-template <int NB>
+template <int NB, int W>
 __device__ __forceinline__ void ss_store_partial(float (&s1)[NB][16], float (&s2)[NB][16], double* __restrict__ part, float* lds) {
     const int w = wave_id(), lane = lane_id(), h = lane >> 5;
     __syncthreads();                                   // the tile loop's LDS traffic is over in every wave
-    for (int e = threadIdx.x; e < SS_WAVES * 128; e += blockDim.x) lds[e] = 0.f;
+    for (int e = threadIdx.x; e < W * 128; e += blockDim.x) lds[e] = 0.f;
     __syncthreads();
 #pragma unroll
     for (int b = 0; b < NB; ++b)
@@ -241,13 +242,13 @@ __device__ __forceinline__ void ss_store_partial(float (&s1)[NB][16], float (&s2
     if (threadIdx.x < 128) {
         double a = 0.0;
 #pragma unroll
-        for (int ww = 0; ww < SS_WAVES; ++ww) a += (double)lds[ww * 128 + threadIdx.x];
+        for (int ww = 0; ww < W; ++ww) a += (double)lds[ww * 128 + threadIdx.x];
         part[threadIdx.x] = a;
     }
 }
 
 // the wave's weight-gradient accumulators (rows = output channels, lane & 31 = input channel) -> workgroup partial [64][32]
-template <int NB>
+template <int NB, int W>
 __device__ __forceinline__ void ss_store_dw(const f32x16 (&dw)[NB], float* __restrict__ part, float* lds) {
     const int w = wave_id(), lane = lane_id(), h = lane >> 5, j = lane & 31;
     __syncthreads();
@@ -259,7 +260,7 @@ __device__ __forceinline__ void ss_store_dw(const f32x16 (&dw)[NB], float* __res
     for (int e = threadIdx.x; e < NB * 1024; e += blockDim.x) {
         float a = lds[e];
 #pragma unroll
-        for (int ww = 1; ww < SS_WAVES; ++ww) a += lds[ww * SS_DW + e];
+        for (int ww = 1; ww < W; ++ww) a += lds[ww * SS_DW + e];
         part[e] = a;
     }
 }
@@ -277,6 +278,7 @@ __device__ __forceinline__ void ss_dw_tile(f32x16 (&dw)[NB], const float* __rest
     const int h = lane >> 5, c = lane & 31;
 #pragma unroll
     for (int t = 0; t < 16; ++t) {
+        if ((t & 3) == 0) __builtin_amdgcn_sched_barrier(0);      // at most four k-steps of operand reads in flight: registers
         const float b = yt[c * SS_LD + 2 * t + h];
 #pragma unroll
         for (int rb = 0; rb < NB; ++rb)
@@ -286,22 +288,34 @@ __device__ __forceinline__ void ss_dw_tile(f32x16 (&dw)[NB], const float* __rest
 
 __device__ __forceinline__ void ss_wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// packed weights and per-channel state -> LDS, once per workgroup
+__device__ __forceinline__ void ss_stage_constants(const SsParams& p, float* smem, int R3) {
+    const int nw = ss_wpack_floats(R3);
+    for (int e = threadIdx.x * 4; e < nw; e += blockDim.x * 4)
+        *reinterpret_cast<float4*>(smem + e) = *reinterpret_cast<const float4*>(p.wpack + e);
+    for (int e = threadIdx.x * 4; e < SS_LDS_STATE; e += blockDim.x * 4)
+        *reinterpret_cast<float4*>(smem + SS_LDS_WPACK + e) = *reinterpret_cast<const float4*>(p.state + e);
+    __syncthreads();
+}
+
 // ---- forward passes ---------------------------------------------------------------------------------------------------
 // STAGE 1..3: statistics of layer STAGE's pre-activation; STAGE 4: pooled output.  NS = nsample (16 | 32), R3 = c3 / 32.
-template <int R3, int NS, int STAGE>
-__global__ __launch_bounds__(SS_WAVES * 64) void ss_fwd_kernel(const SsParams p) {
-    __shared__ float lds_all[SS_WAVES * SS_LDS_WAVE];
+template <int R3, int NS, int STAGE, int W>
+__global__ __launch_bounds__(W * 64) void ss_fwd_kernel(const SsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = wave_id(), lane = lane_id(), h = lane >> 5, j = lane & 31;
+    float* lds_all = smem + SS_LDS_WPACK + SS_LDS_STATE;
     float* lds = lds_all + w * SS_LDS_WAVE;
+    ss_stage_constants(p, smem, R3);
     SsFrag<4, 1> w1;
     SsFrag<16, 1> w2;
     SsFrag<16, R3> w3;
-    w1.load(p.wpack, lane);
-    if (STAGE >= 2) w2.load(p.wpack + ss_off_w2(), lane);
-    if (STAGE >= 3) w3.load(p.wpack + ss_off_w3(), lane);
-    const float* st1 = p.state + ss_state_base(1);
-    const float* st2 = p.state + ss_state_base(2);
-    const float* st3 = p.state + ss_state_base(3);
+    w1.load(smem, lane);
+    w2.load(smem + ss_off_w2(), lane);
+    w3.load(smem + ss_off_w3(), lane);
+    const float* st1 = smem + SS_LDS_WPACK + ss_state_base(1);
+    const float* st2 = smem + SS_LDS_WPACK + ss_state_base(2);
+    const float* st3 = smem + SS_LDS_WPACK + ss_state_base(3);
     constexpr int NB = STAGE == 3 ? R3 : 1;
     float s1[NB][16], s2[NB][16];
 #pragma unroll
@@ -314,9 +328,10 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_fwd_kernel(const SsParams p)
     if (STAGE == 4) { emu = st3[ech]; eis = st3[32 * R3 + ech]; ega = st3[64 * R3 + ech]; ebe = st3[96 * R3 + ech]; }
 
     SsWalk walk;
-    walk.start(p, (int64_t)blockIdx.x * SS_WAVES + w, (int64_t)gridDim.x * SS_WAVES, j, h);
+    walk.start(p, (int64_t)blockIdx.x * W + w, (int64_t)gridDim.x * W, j, h);
     for (; walk.tile < p.tiles; walk.tile += walk.stride) {
         const int64_t tile = walk.tile;
+        asm volatile("" ::: "memory");     // weights and per-channel constants are re-read from LDS per tile, not hoisted into registers
         float x0[4];
         walk.fetch(p, j, h, x0);
         f32x16 a1[1], a2[1], a3[R3], dummy;
@@ -360,7 +375,7 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_fwd_kernel(const SsParams p)
         p.arg[tile * 64 + lane] = (uint8_t)bs;
         ss_wave_fence();                  // my reads are done before the next tile's writes
     }
-    if (STAGE <= 3) ss_store_partial<NB>(s1, s2, p.partial + (size_t)blockIdx.x * SS_PART, lds_all);
+    if (STAGE <= 3) ss_store_partial<NB, W>(s1, s2, p.partial + (size_t)blockIdx.x * SS_PART, lds_all);
 }
 
 // ---- backward passes --------------------------------------------------------------------------------------------------
@@ -399,11 +414,13 @@ __global__ __launch_bounds__(256) void ss_pool_sums_kernel(const float* __restri
 }
 
 // STAGE 3: down from the pooled gradient to dz2'; STAGE 2: from dz2' to dz1'; STAGE 1: from dz1' to dW1.
-template <int R3, int NS, int STAGE>
-__global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p) {
-    __shared__ float lds_all[SS_WAVES * SS_LDS_WAVE];
+template <int R3, int NS, int STAGE, int W>
+__global__ __launch_bounds__(W * 64) void ss_bwd_kernel(const SsParams p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int w = wave_id(), lane = lane_id(), h = lane >> 5, j = lane & 31;
+    float* lds_all = smem + SS_LDS_WPACK + SS_LDS_STATE;
     float* lds = lds_all + w * SS_LDS_WAVE;
+    ss_stage_constants(p, smem, R3);
     float* zt = lds;                      // [<= 64][33]: the gradient block(s), transposed
     float* yt = lds + 64 * SS_LD;         // [32][33]: the activation block, transposed
     SsFrag<4, 1> w1;
@@ -411,13 +428,14 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
     SsFrag<16, R3> w3;
     SsFrag<16, 1> w2t;
     SsFrag<16 * R3, 1> w3t;
-    w1.load(p.wpack, lane);
-    if (STAGE >= 2) { w2.load(p.wpack + ss_off_w2(), lane); }
-    if (STAGE == 2) { w2t.load(p.wpack + ss_off_w2t(R3), lane); }
-    if (STAGE == 3) { w3.load(p.wpack + ss_off_w3(), lane); w3t.load(p.wpack + ss_off_w3t(R3), lane); }
-    const float* st1 = p.state + ss_state_base(1);
-    const float* st2 = p.state + ss_state_base(2);
-    const float* st3 = p.state + ss_state_base(3);
+    w1.load(smem, lane);
+    w2.load(smem + ss_off_w2(), lane);
+    w2t.load(smem + ss_off_w2t(R3), lane);
+    w3.load(smem + ss_off_w3(), lane);
+    w3t.load(smem + ss_off_w3t(R3), lane);
+    const float* st1 = smem + SS_LDS_WPACK + ss_state_base(1);
+    const float* st2 = smem + SS_LDS_WPACK + ss_state_base(2);
+    const float* st3 = smem + SS_LDS_WPACK + ss_state_base(3);
     constexpr int NBW = STAGE == 3 ? R3 : 1;          // row blocks of this pass's weight gradient
     f32x16 dw[NBW];
 #pragma unroll
@@ -435,24 +453,18 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
     const int cup = STAGE == 2 ? p.c2 : p.c1;         // ... and of the one it reads (STAGE <= 2)
 
     SsWalk walk;
-    walk.start(p, (int64_t)blockIdx.x * SS_WAVES + w, (int64_t)gridDim.x * SS_WAVES, j, h);
+    walk.start(p, (int64_t)blockIdx.x * W + w, (int64_t)gridDim.x * W, j, h);
     for (; walk.tile < p.tiles; walk.tile += walk.stride) {
         const int64_t tile = walk.tile;
         const int64_t tok = tile * 32 + j;
+        asm volatile("" ::: "memory");     // weights and per-channel constants are re-read from LDS per tile, not hoisted into registers
         float x0[4];
         walk.fetch(p, j, h, x0);
         // the gradient this pass starts from, requested before the recompute chain
         const int64_t g = NS == 32 ? tile : tile * 2 + (j >> 4);
-        float4 gin[STAGE == 3 ? R3 : 1][4];
-        uchar4 ain[STAGE == 3 ? R3 : 1][4];
+        float4 gin[1][4];
         if constexpr (STAGE == 3) {
-#pragma unroll
-            for (int rb = 0; rb < R3; ++rb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    gin[rb][q] = *reinterpret_cast<const float4*>(p.gout + g * p.c3 + rb * 32 + 8 * q + 4 * h);
-                    ain[rb][q] = *reinterpret_cast<const uchar4*>(p.arg_in + g * p.c3 + rb * 32 + 8 * q + 4 * h);
-                }
+            // (loaded where they are used: with two waves per SIMD the other wave covers the latency, and 40 registers matter)
         } else {
             const float* row = p.dz_in + tok * cup;
 #pragma unroll
@@ -474,11 +486,12 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
             for (int rb = 0; rb < R3; ++rb)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    asm volatile("" ::: "memory");     // one (rb, q) group of loads at a time: registers
                     const SsChan c = ss_chan(st3, 32 * R3, rb, q, h);
                     const float4 m1 = *reinterpret_cast<const float4*>(st3 + 4 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
                     const float4 m2 = *reinterpret_cast<const float4*>(st3 + 5 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
-                    const float4 go = gin[rb][q];
-                    const uchar4 ar = ain[rb][q];
+                    const float4 go = *reinterpret_cast<const float4*>(p.gout + g * p.c3 + rb * 32 + 8 * q + 4 * h);
+                    const uchar4 ar = *reinterpret_cast<const uchar4*>(p.arg_in + g * p.c3 + rb * 32 + 8 * q + 4 * h);
                     const int av[4] = {ar.x, ar.y, ar.z, ar.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -541,8 +554,8 @@ __global__ __launch_bounds__(SS_WAVES * 64) void ss_bwd_kernel(const SsParams p)
             }
         }
     }
-    if (STAGE >= 2) ss_store_partial<1>(s1, s2, p.partial + (size_t)blockIdx.x * SS_PART, lds_all);
-    ss_store_dw<NBW>(dw, p.dw_partial + (size_t)blockIdx.x * SS_DW, lds_all);
+    if (STAGE >= 2) ss_store_partial<1, W>(s1, s2, p.partial + (size_t)blockIdx.x * SS_PART, lds_all);
+    ss_store_dw<NBW, W>(dw, p.dw_partial + (size_t)blockIdx.x * SS_DW, lds_all);
 }
 
 // ---- finalize kernels (one workgroup of 1024 threads = 64 channels x 16 slices of the partials) -----------------------
@@ -623,26 +636,50 @@ __global__ __launch_bounds__(1024) void ss_finalize_bwd_kernel(const double* __r
     }
 }
 
-static int ss_blocks(int64_t tiles, int cap = SS_MAX_BLOCKS) {
-    const int64_t want = divup64(tiles, SS_WAVES);
-    return (int)(want < cap ? want : cap);
+template <typename K>
+static bool ss_lds_ok(K kern, PerDevice<bool>& once, int bytes) {
+    return once.get([kern, bytes] { return hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess; });
+}
+static int ss_blocks_for(int64_t tiles, int waves) {      // one workgroup per CU (LDS), every wave walks >= 1 tile
+    const int64_t want = divup64(tiles, waves);
+    return (int)(want < 256 ? want : 256);
 }
 
-template <int R3, int NS>
-static void ss_launch_fwd(int stage, const SsParams& p, int blocks, hipStream_t s) {
-    switch (stage) {
-        case 1: hipLaunchKernelGGL((ss_fwd_kernel<R3, NS, 1>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((ss_fwd_kernel<R3, NS, 2>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((ss_fwd_kernel<R3, NS, 3>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-        default: hipLaunchKernelGGL((ss_fwd_kernel<R3, NS, 4>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-    }
+template <int R3, int NS, int STAGE>
+static bool ss_launch_fwd_stage(const SsParams& p, hipStream_t s, int& blocks) {
+    constexpr int W = SS_WAVES;
+    static PerDevice<bool> once;
+    constexpr int bytes = ss_lds_floats(W) * (int)sizeof(float);
+    if (!ss_lds_ok(ss_fwd_kernel<R3, NS, STAGE, W>, once, bytes)) return false;
+    blocks = ss_blocks_for(p.tiles, W);
+    hipLaunchKernelGGL((ss_fwd_kernel<R3, NS, STAGE, W>), dim3(blocks), dim3(W * 64), bytes, s, p);
+    return true;
 }
 template <int R3, int NS>
-static void ss_launch_bwd(int stage, const SsParams& p, int blocks, hipStream_t s) {
+static bool ss_launch_fwd(int stage, const SsParams& p, hipStream_t s, int& blocks) {
     switch (stage) {
-        case 3: hipLaunchKernelGGL((ss_bwd_kernel<R3, NS, 3>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-        case 2: hipLaunchKernelGGL((ss_bwd_kernel<R3, NS, 2>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
-        default: hipLaunchKernelGGL((ss_bwd_kernel<R3, NS, 1>), dim3(blocks), dim3(SS_WAVES * 64), 0, s, p); break;
+        case 1: return ss_launch_fwd_stage<R3, NS, 1>(p, s, blocks);
+        case 2: return ss_launch_fwd_stage<R3, NS, 2>(p, s, blocks);
+        case 3: return ss_launch_fwd_stage<R3, NS, 3>(p, s, blocks);
+        default: return ss_launch_fwd_stage<R3, NS, 4>(p, s, blocks);
+    }
+}
+template <int R3, int NS, int STAGE>
+static bool ss_launch_bwd_stage(const SsParams& p, hipStream_t s, int& blocks) {
+    constexpr int W = (STAGE == 3 && R3 == 2) ? SS_WAVES_HEAVY : SS_WAVES;
+    static PerDevice<bool> once;
+    constexpr int bytes = ss_lds_floats(W) * (int)sizeof(float);
+    if (!ss_lds_ok(ss_bwd_kernel<R3, NS, STAGE, W>, once, bytes)) return false;
+    blocks = ss_blocks_for(p.tiles, W);
+    hipLaunchKernelGGL((ss_bwd_kernel<R3, NS, STAGE, W>), dim3(blocks), dim3(W * 64), bytes, s, p);
+    return true;
+}
+template <int R3, int NS>
+static bool ss_launch_bwd(int stage, const SsParams& p, hipStream_t s, int& blocks) {
+    switch (stage) {
+        case 3: return ss_launch_bwd_stage<R3, NS, 3>(p, s, blocks);
+        case 2: return ss_launch_bwd_stage<R3, NS, 2>(p, s, blocks);
+        default: return ss_launch_bwd_stage<R3, NS, 1>(p, s, blocks);
     }
 }
 
@@ -697,11 +734,11 @@ PDA_API int pda_sa_small_train_fwd(const float* xyz, const float* new_xyz, const
     p.n = n; p.m = m; p.c = c; p.ns = ns; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     const int64_t tokens = (int64_t)b * m * ns;
     p.tiles = tokens / 32;
-    const int blocks = ss_blocks(p.tiles);
+    int blocks = 0;
     const int cs[3] = {c1, c2, c3}, Ps[3] = {32, 32, 32 * R3};
     for (int stage = 1; stage <= 4; ++stage) {
-        if (R3 == 1) ss_launch_fwd<1, 16>(stage, p, blocks, s);
-        else ss_launch_fwd<2, 32>(stage, p, blocks, s);
+        const bool ok = R3 == 1 ? ss_launch_fwd<1, 16>(stage, p, s, blocks) : ss_launch_fwd<2, 32>(stage, p, s, blocks);
+        PDA_REQUIRE(ok, "pda_sa_small_train_fwd: dynamic LDS refused");
         if (stage <= 3)
             hipLaunchKernelGGL(ss_finalize_fwd_kernel, dim3(1), dim3(1024), 0, s, (const double*)p.partial, blocks, cs[stage - 1],
                                Ps[stage - 1], tokens, eps[stage - 1], momentum[stage - 1], gamma[stage - 1], beta[stage - 1],
@@ -729,7 +766,7 @@ PDA_API int pda_sa_small_train_bwd(const float* xyz, const float* new_xyz, const
     p.n = n; p.m = m; p.c = c; p.ns = ns; p.c1 = c1; p.c2 = c2; p.c3 = c3;
     const int64_t tokens = (int64_t)b * m * ns, groups = (int64_t)b * m;
     p.tiles = tokens / 32;
-    const int blocks = ss_blocks(p.tiles, 256);      // the heavy passes hold one wave per SIMD: one workgroup per CU
+    int blocks = 0;
     const int R3 = c3 / 32;
     // E0: BatchNorm-3 backward sums from the pooled side
     const int pb = (int)(divup64(groups, 256 / (c3 / 4)) < 256 ? divup64(groups, 256 / (c3 / 4)) : 256);
@@ -739,17 +776,20 @@ PDA_API int pda_sa_small_train_bwd(const float* xyz, const float* new_xyz, const
                        state + ss_state_base(3), dgamma[2], dbeta[2], (const float*)nullptr, 0, 0, 0, (float*)nullptr);
     // B3: dW3, dz2', BatchNorm-2 sums
     p.dz_out = dz2;
-    if (R3 == 1) ss_launch_bwd<1, 16>(3, p, blocks, s); else ss_launch_bwd<2, 32>(3, p, blocks, s);
+    { const bool ok = R3 == 1 ? ss_launch_bwd<1, 16>(3, p, s, blocks) : ss_launch_bwd<2, 32>(3, p, s, blocks);
+      PDA_REQUIRE(ok, "pda_sa_small_train_bwd: dynamic LDS refused"); }
     hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c3 * c2, 64)), dim3(1024), 0, s, (const double*)p.partial, blocks, c2, 32, tokens,
                        state + ss_state_base(2), dgamma[1], dbeta[1], (const float*)p.dw_partial, blocks, c3, c2, dw3);
     // B2: dW2, dz1', BatchNorm-1 sums
     p.dz_in = dz2; p.dz_out = dz1;
-    if (R3 == 1) ss_launch_bwd<1, 16>(2, p, blocks, s); else ss_launch_bwd<2, 32>(2, p, blocks, s);
+    { const bool ok = R3 == 1 ? ss_launch_bwd<1, 16>(2, p, s, blocks) : ss_launch_bwd<2, 32>(2, p, s, blocks);
+      PDA_REQUIRE(ok, "pda_sa_small_train_bwd: dynamic LDS refused"); }
     hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c2 * c1, 64)), dim3(1024), 0, s, (const double*)p.partial, blocks, c1, 32, tokens,
                        state + ss_state_base(1), dgamma[0], dbeta[0], (const float*)p.dw_partial, blocks, c2, c1, dw2);
     // B1: dW1
     p.dz_in = dz1; p.dz_out = nullptr;
-    if (R3 == 1) ss_launch_bwd<1, 16>(1, p, blocks, s); else ss_launch_bwd<2, 32>(1, p, blocks, s);
+    { const bool ok = R3 == 1 ? ss_launch_bwd<1, 16>(1, p, s, blocks) : ss_launch_bwd<2, 32>(1, p, s, blocks);
+      PDA_REQUIRE(ok, "pda_sa_small_train_bwd: dynamic LDS refused"); }
     hipLaunchKernelGGL(ss_finalize_bwd_kernel, dim3(1 + divup(c1 * (3 + c), 64)), dim3(1024), 0, s, (const double*)nullptr, 0, 0, 0, tokens,
                        (float*)nullptr, (float*)nullptr, (float*)nullptr, (const float*)p.dw_partial, blocks, c1, 3 + c, dw1);
     return check_launch("pda_sa_small_train_bwd");

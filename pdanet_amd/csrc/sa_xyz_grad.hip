@@ -89,12 +89,23 @@ __global__ __launch_bounds__(XG_THREADS) void sa_xyz_grad_kernel(const float* __
     }
 }
 
+// 16 elements x 16 slices of the workgroup partials per block, slices summed in fixed order
 __global__ __launch_bounds__(256) void sa_xyz_grad_reduce_kernel(const float* __restrict__ partial, int nblocks, int c1, float* __restrict__ dw, int lddw) {
-    const int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= c1 * 3) return;
+    __shared__ double red[16][16];
+    const int el = threadIdx.x & 15, part = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const bool ok = e < c1 * 3;
     double a = 0.0;
-    for (int k = 0; k < nblocks; ++k) a += (double)partial[(size_t)k * c1 * 3 + e];
-    dw[(size_t)(e / 3) * lddw + e % 3] = (float)a;
+    if (ok)
+        for (int k = part; k < nblocks; k += 16) a += (double)partial[(size_t)k * c1 * 3 + e];
+    red[part][el] = a;
+    __syncthreads();
+    if (part == 0 && ok) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q][el];
+        dw[(size_t)(e / 3) * lddw + e % 3] = (float)t;
+    }
 }
 
 }  // namespace pda
@@ -121,6 +132,6 @@ PDA_API int pda_sa_xyz_grad(const float* grad_z1, const float* xyz, const float*
                                        partial, grad_new_xyz, n, m, ns, c1, groups)
     if (cpt == 1) PDA_XG(1); else if (cpt == 2) PDA_XG(2); else PDA_XG(4);
 #undef PDA_XG
-    hipLaunchKernelGGL(sa_xyz_grad_reduce_kernel, dim3(divup(c1 * 3, 256)), dim3(256), 0, s, (const float*)partial, blocks, c1, dw, lddw);
+    hipLaunchKernelGGL(sa_xyz_grad_reduce_kernel, dim3(divup(c1 * 3, 16)), dim3(256), 0, s, (const float*)partial, blocks, c1, dw, lddw);
     return check_launch("pda_sa_xyz_grad");
 }

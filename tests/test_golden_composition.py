@@ -308,11 +308,19 @@ def test_backbone_prefetch_starts_the_next_forward_early_and_changes_nothing():
         return bd['centers'].clone(), bd['centers_features'].clone(), bd['encoder_xyz'][2].clone()
     ref, ref_other = run(pts), run(other)
     model.prefetch(pts, 2)
-    assert model._prefetched is not None
+    assert len(model._prefetched) == 1
     got = run(pts)                               # consumes the stash
-    assert model._prefetched is None
+    assert len(model._prefetched) == 0
     model.prefetch(pts, 2)
     got_other = run(other)                       # stash belongs to another batch: dropped, computed afresh
+    assert len(model._prefetched) == 0
+    # two batches in flight (a serving loop prefetches batch i + 1 BEFORE the forward of batch i): consumed oldest first
+    model.prefetch(pts, 2)
+    model.prefetch(other, 2)
+    a1, a2 = run(pts), run(other)
+    assert len(model._prefetched) == 0
+    for a, b in zip(ref + ref_other, a1 + a2):
+        assert torch.equal(a, b)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
     for a, b in zip(ref_other, got_other):
