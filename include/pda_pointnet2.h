@@ -228,6 +228,10 @@ int pda_sa_gather_linear(const float *xyz, const float *new_xyz, const float *fe
  * PDA_ERR_UNSUPPORTED for other shapes. */
 int64_t pda_linear_split_packed_bytes(int n_out, int k);
 int pda_linear_split_pack(const float *w, void *wf, int n_out, int k, int transposed_source, pda_stream_t stream);
+/* Both forms a training step needs of one weight W (n_out, k), packed in one launch: wf = the planes of W (as
+ * pda_linear_split_pack(w, wf, n_out, k, 0)), wft = the planes of W^T from the same source (as
+ * pda_linear_split_pack(w, wft, k, n_out, 1): the weights of dX = dY W). */
+int pda_linear_split_pack_both(const float *w, void *wf, void *wft, int n_out, int k, pda_stream_t stream);
 int pda_linear_split(const float *x, const void *wf, const float *bias, float *y, int64_t tokens, int k, int n_out,
                      int relu, pda_stream_t stream);
 /* The same arithmetic as an LDS-tiled GEMM (gemm_split_kernel): any k that is a multiple of 32, any n_out (the planes of

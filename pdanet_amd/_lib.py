@@ -15,6 +15,9 @@ ABI_VERSION = 18
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
 # copies, BatchNorm folded into convolutions) key on it next to the version counters.
 PARAM_EPOCH = [0]
+# The same for the trained PARAMETERS only (bumped by the optimizer step, not by BatchNorm running statistics): packed weight
+# planes made in a forward pass stay valid until the next optimizer step, i.e. through the backward pass of the same iteration.
+WEIGHT_EPOCH = [0]
 
 _vp = ctypes.c_void_p
 _i = ctypes.c_int
@@ -55,6 +58,7 @@ SIGNATURES = {
     "pda_sa_gather_linear": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "pda_linear_split_packed_bytes": [_i, _i],
     "pda_linear_split_pack": [_vp, _vp, _i, _i, _i, _vp],
+    "pda_linear_split_pack_both": [_vp, _vp, _vp, _i, _i, _vp],
     "pda_linear_split": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_gemm_split": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _i, _vp],
     "pda_sa_mlp_packed_size": [_i, _i, _i],

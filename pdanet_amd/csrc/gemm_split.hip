@@ -33,23 +33,38 @@ constexpr int GS_MAX_N = 2048;                   // widest output (bias staged i
 constexpr int GS_KSTEP = 12 * 64;                // uint4 per k-step of a 128-output chunk (4 row blocks x 3 planes x 64 lanes)
 
 // W (rows, cols) row-major (trans: the source holds W^T, (cols, rows) row-major) -> fragment-ordered planes.
+__device__ __forceinline__ void split_pack_one(const float* __restrict__ w, uint32_t* __restrict__ wf, int64_t o, int rows, int cols,
+                                               int KS, int trans) {
+    const int pr = (int)(o & 3), lane = (int)((o >> 2) & 63);
+    int64_t rest = o >> 8;
+    const int rb = (int)(rest & 3); rest >>= 2;
+    const int s = (int)(rest % KS), c = (int)(rest / KS);
+    const int row = c * 128 + rb * 32 + (lane & 31);
+    const int k = 16 * s + 8 * (lane >> 5) + 2 * pr;
+    float v[2];
+    for (int e = 0; e < 2; ++e)
+        v[e] = (row < rows && k + e < cols) ? (trans ? w[(size_t)(k + e) * rows + row] : w[(size_t)row * cols + k + e]) : 0.f;
+    uint32_t h, m, l;
+    split2(v[0], v[1], h, m, l);
+    const size_t base = ((((size_t)c * KS + s) * 4 + rb) * 3) * 256 + (size_t)lane * 4 + pr;    // uint32 units
+    wf[base] = h; wf[base + 256] = m; wf[base + 512] = l;
+}
+
 __global__ void split_pack_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf, int rows, int cols, int KS,
                                   int chunks, int trans) {
     const int64_t total = (int64_t)chunks * KS * 4 * 64 * 4;       // one thread per (chunk, s, rb, lane, pair)
-    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x) {
-        const int pr = (int)(o & 3), lane = (int)((o >> 2) & 63);
-        int64_t rest = o >> 8;
-        const int rb = (int)(rest & 3); rest >>= 2;
-        const int s = (int)(rest % KS), c = (int)(rest / KS);
-        const int row = c * 128 + rb * 32 + (lane & 31);
-        const int k = 16 * s + 8 * (lane >> 5) + 2 * pr;
-        float v[2];
-        for (int e = 0; e < 2; ++e)
-            v[e] = (row < rows && k + e < cols) ? (trans ? w[(size_t)(k + e) * rows + row] : w[(size_t)row * cols + k + e]) : 0.f;
-        uint32_t h, m, l;
-        split2(v[0], v[1], h, m, l);
-        const size_t base = ((((size_t)c * KS + s) * 4 + rb) * 3) * 256 + (size_t)lane * 4 + pr;    // uint32 units
-        wf[base] = h; wf[base + 256] = m; wf[base + 512] = l;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total; o += (int64_t)gridDim.x * blockDim.x)
+        split_pack_one(w, wf, o, rows, cols, KS, trans);
+}
+
+// Both forms a training step needs of one weight W (n_out, k) in ONE launch: the planes of W (forward, Y = X W^T) and of
+// W^T packed from the same source (input gradient, dX = dY W).
+__global__ void split_pack_both_kernel(const float* __restrict__ w, uint32_t* __restrict__ wf, uint32_t* __restrict__ wft, int n_out,
+                                       int k, int KS, int chunks, int KSt, int chunks_t) {
+    const int64_t total = (int64_t)chunks * KS * 4 * 64 * 4, total_t = (int64_t)chunks_t * KSt * 4 * 64 * 4;
+    for (int64_t o = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; o < total + total_t; o += (int64_t)gridDim.x * blockDim.x) {
+        if (o < total) split_pack_one(w, wf, o, n_out, k, KS, 0);
+        else split_pack_one(w, wft, o - total, k, n_out, KSt, 1);
     }
 }
 
@@ -543,6 +558,17 @@ PDA_API int pda_linear_split_pack(const float* w, void* wf, int n_out, int k, in
     hipLaunchKernelGGL(pda::split_pack_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint32_t*)wf, n_out, k, KS,
                        chunks, transposed_source);
     return pda::check_launch("pda_linear_split_pack");
+}
+
+PDA_API int pda_linear_split_pack_both(const float* w, void* wf, void* wft, int n_out, int k, pda_stream_t stream) {
+    PDA_REQUIRE(w && wf && wft && n_out > 0 && k > 0, "pda_linear_split_pack_both: bad argument");
+    const int chunks = pda::divup(n_out, 128), KS = pda::divup(k, 32) * 2;
+    const int chunks_t = pda::divup(k, 128), KSt = pda::divup(n_out, 32) * 2;
+    const int64_t total = ((int64_t)chunks * KS + (int64_t)chunks_t * KSt) * 4 * 64 * 4;
+    const int blocks = (int)(pda::divup64(total, 256) < 2048 ? pda::divup64(total, 256) : 2048);
+    hipLaunchKernelGGL(pda::split_pack_both_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, (uint32_t*)wf, (uint32_t*)wft,
+                       n_out, k, KS, chunks, KSt, chunks_t);
+    return pda::check_launch("pda_linear_split_pack_both");
 }
 
 PDA_API int pda_linear_split(const float* x, const void* wf, const float* bias, float* y, int64_t tokens, int k, int n_out,

@@ -160,6 +160,7 @@ class FlatAdamOneCycle:
                 for t in [p.data for p in model.parameters() if id(p) not in mine] + list(model.buffers()):
                     dist.broadcast(t, src, group=group)
             _lib.PARAM_EPOCH[0] += 1
+            _lib.WEIGHT_EPOCH[0] += 1
         return self
 
     def exchange_gradients(self):
@@ -225,6 +226,7 @@ class FlatAdamOneCycle:
                 norm_ptr = self._norm.data_ptr()
             self.step_count += 1
             _lib.PARAM_EPOCH[0] += 1        # parameters change without their version counters moving
+            _lib.WEIGHT_EPOCH[0] += 1
             _lib.check(lib.pda_adam_onecycle_step(
                 self.flat_p.data_ptr(), self.flat_g.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 self.n_trained, self.lr, self.mom, self.beta2, self.eps, self.wd, self.step_count, norm_ptr,

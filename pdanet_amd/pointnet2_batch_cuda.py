@@ -618,6 +618,15 @@ def linear_split_pack(w, n_out, k, transposed_source=False):
     return wf
 
 
+def linear_split_pack_both(w, n_out, k):
+    """(planes of W, planes of W^T) of one weight W (n_out, k) in one launch (csrc/gemm_split.hip)."""
+    wf = torch.empty((_split_packed_bytes(int(n_out), int(k)),), dtype=torch.uint8, device=w.device)
+    wft = torch.empty((_split_packed_bytes(int(k), int(n_out)),), dtype=torch.uint8, device=w.device)
+    _numel_ok(w, n_out * k, "w")
+    _call("pda_linear_split_pack_both", w, _chk(w, "w", F32), _chk(wf, "wf", torch.uint8), _chk(wft, "wft", torch.uint8), n_out, k)
+    return wf, wft
+
+
 def linear_split(x, wf, bias, y, tokens, k, n_out, relu=False):
     _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
     _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")

@@ -572,6 +572,57 @@ def _rows_in_registers(tokens, k, n_out):
     return k <= 256 and n_out % 128 == 0 and n_out <= 2048 and tokens < 98304
 
 
+# Packed bf16 planes of the PARAMETER weights, keyed on the storage address: {ptr: (tag, planes of W, planes of W^T, weak
+# reference to the owning nn.Parameter, byte offset of the weight inside it)} with tag = (version counter,
+# _lib.WEIGHT_EPOCH, shape).  Training packs both forms in one launch in the forward pass; the backward pass (which sees
+# the weight as an unpacked saved tensor, not as the Parameter) finds the transposed planes by address.  An entry is valid
+# only while its Parameter is alive AND still sits at that address -- then no other tensor can occupy it; a freed model or a
+# re-pointed `.data` (optimization.FlatAdamOneCycle moves the parameters into its flat buffer) invalidates it.  Inference
+# packs once and hits until the weights change.
+_PACKED_PLANES = {}
+
+
+def _owning_parameter(w):
+    if isinstance(w, nn.Parameter):
+        return w
+    base = getattr(w, "_base", None)
+    return base if isinstance(base, nn.Parameter) else None
+
+
+def _split_planes(w, transposed=False):
+    """Planes of W (n_out, k) for Y = X W^T (transposed=False) or of W^T for dX = dY W (True); w is the (n_out, k) source."""
+    n_out, k = w.shape
+    wd = w.detach()
+
+    def pack(t):
+        src = wd if wd.is_contiguous() else wd.contiguous()
+        return pointnet2.linear_split_pack(src, k, n_out, transposed_source=True) if t else pointnet2.linear_split_pack(src, n_out, k)
+    if not wd.is_contiguous():
+        return pack(transposed)
+    key, tag = wd.data_ptr(), (wd._version, _lib.WEIGHT_EPOCH[0], n_out, k)
+    ent = _PACKED_PLANES.get(key)
+    if ent is not None:
+        owner = ent[3]()
+        if owner is None or owner.data_ptr() + ent[4] != key:
+            del _PACKED_PLANES[key]                       # the parameter is gone or lives elsewhere now
+            ent = None
+        elif ent[0] != tag:
+            ent = None                                    # the weights changed: repack below (if this is the parameter)
+        elif ent[2 if transposed else 1] is not None:
+            return ent[2 if transposed else 1]
+    param = _owning_parameter(w)
+    if param is None:
+        return pack(transposed)
+    if w.requires_grad and n_out % 32 == 0 and k >= 128:               # (grad mode is off inside Function.forward: ask the tensor)
+        wf, wft = pointnet2.linear_split_pack_both(wd, n_out, k)       # the backward pass of this iteration wants W^T
+    elif transposed:
+        wf, wft = (ent[1] if ent is not None else None), pack(True)
+    else:
+        wf, wft = pack(False), (ent[2] if ent is not None else None)
+    _PACKED_PLANES[key] = (tag, wf, wft, weakref.ref(param), key - param.data_ptr())
+    return wft if transposed else wf
+
+
 def _gemm_nt(x2d, w, bias=None, relu=False):
     """relu?(x2d (T, K) @ w (N, K)^T + bias) in f32."""
     n_out, k = w.shape
@@ -579,7 +630,7 @@ def _gemm_nt(x2d, w, bias=None, relu=False):
         x2d = x2d.contiguous()
         T = x2d.shape[0]
         y = torch.empty((T, n_out), dtype=torch.float32, device=x2d.device)
-        wf = pointnet2.linear_split_pack(w.detach().contiguous(), n_out, k)
+        wf = _split_planes(w)
         bias = None if bias is None else bias.detach().contiguous()
         if _rows_in_registers(T, k, n_out):
             pointnet2.linear_split(x2d, wf, bias, y, T, k, n_out, relu=relu)
@@ -599,7 +650,7 @@ def _gemm_nn(g2d, w, acc=None):
         g2d = g2d.contiguous()
         T = g2d.shape[0]
         y = acc if acc is not None else torch.empty((T, k_out), dtype=torch.float32, device=g2d.device)
-        wf = pointnet2.linear_split_pack(w.detach().contiguous(), k_out, n, transposed_source=True)
+        wf = _split_planes(w, transposed=True)
         if acc is None and _rows_in_registers(T, n, k_out):
             pointnet2.linear_split(g2d, wf, None, y, T, n, k_out)
         else:
@@ -882,7 +933,7 @@ def _sa_timed(flops, fn, pipe="f32"):
 def _lin_cols(x2, weight, y, T, k, n_out, transposed):
     """y (T, n_out) = x2 (T, k) W'^T with W' = weight (n_out, k), or weight^T when `transposed` (weight is (k, n_out))."""
     if SPLIT_GEMM:
-        wf = pointnet2.linear_split_pack(weight, n_out, k, transposed_source=transposed)
+        wf = _split_planes(weight, transposed)       # `weight` is the parameter's (out, in) source either way
         if _rows_in_registers(T, k, n_out):
             _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.linear_split(x2, wf, None, y, T, k, n_out), "bf16x6")
         else:
