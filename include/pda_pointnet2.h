@@ -92,12 +92,14 @@ int pda_ball_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, 
 int pda_ball_query_dilated(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n,
                            int m, float max_radius, float min_radius, int nsample,
                            pda_stream_t stream);
-/* stands where `ellipsoid_query` (pointnet2_api.cpp:16; ellipsoid_query.cpp:13-76, kernel
- * ellipsoid_query_gpu.cu) stands in the reference's module, so the boundary's name set is complete.
- * No PDA-SSD yaml reaches it (its only call on the PDA path is commented out,
- * pointnet2_utils.py:586-587; the "Ellipsoid" SA class uses the spherical ball query):
- * the entry point validates nothing, launches nothing and returns PDA_ERR_UNSUPPORTED with a message;
- * the Python mirror raises.  idx would be (b,m,nsample), allocated by the caller here. */
+/* replaces `ellipsoid_query` (pointnet2_api.cpp:16; ellipsoid_query.cpp:13-76, kernel ellipsoid_query_gpu.cu:311-498
+ * with the Jacobi eigen-decomposition :58-298).  No PDA-SSD yaml reaches it (its only call on the PDA path is commented
+ * out, pointnet2_utils.py:586-587; the "Ellipsoid" SA class uses the spherical ball query); built so that
+ * every name of the boundary has a kernel.  idx (b, m, nsample) is caller-allocated and ZERO-filled (the reference's
+ * wrapper allocates it with torch::zeros); on return a row holds the ball query of radius e3 extended, for centres with
+ * >= 3 hits, by the unlisted points inside the ellipsoid (e1, e2, e3) oriented along the eigenvectors of the hits'
+ * covariance, in index order, up to nsample.  The reference's work tensors (ingroup_*, v, d) are not materialised.
+ * Parity vs a CUDA build is unpinned for this operator (float expression contraction inside the Jacobi rotations). */
 int pda_ellipsoid_query(const float *new_xyz, const float *xyz, int32_t *idx, int b, int n, int m,
                         float e1, float e2, float e3, int nsample, pda_stream_t stream);
 /* MI355X extension: pda_ball_query_multi through a uniform cell list (csrc/ball_query_cells.hip) -- the same rows,

@@ -22,6 +22,7 @@ from .binding import (  # noqa: F401
     set_num_threads,
     ball_query_wrapper,
     ball_query_dilated_wrapper,
+    ellipsoid_query,
     group_points_wrapper,
     group_points_grad_wrapper,
     gather_points_wrapper,

@@ -74,6 +74,16 @@ def ball_query_wrapper(b, n, m, radius, nsample, new_xyz, xyz, idx):
                                         _i(idx, (b, m, nsample)))
 
 
+def ellipsoid_query(new_xyz, xyz, e1, e2, e3, nsample):
+    """pointnet2_api.cpp:16 / ellipsoid_query.cpp:13-76: allocates (zero-filled) and returns idx (b, m, nsample)."""
+    b, m, _ = new_xyz.shape
+    n = xyz.shape[1]
+    idx = np.zeros((b, m, nsample), np.int32)
+    _lib().pda_oracle_ellipsoid_query(b, n, m, ctypes.c_float(e1), ctypes.c_float(e2), ctypes.c_float(e3), nsample,
+                                      _f(new_xyz, (b, m, 3)), _f(xyz, (b, n, 3)), _i(idx, (b, m, nsample)))
+    return idx
+
+
 def ball_query_dilated_wrapper(b, n, m, max_radius, min_radius, nsample, new_xyz, xyz, idx):
     return _lib().pda_oracle_ball_query_dilated(b, n, m, ctypes.c_float(max_radius),
                                                 ctypes.c_float(min_radius), nsample,

@@ -212,6 +212,165 @@ PDA_EXPORT int pda_oracle_ball_query(int b, int n, int m, float radius, int nsam
     return 1;
 }
 
+/* ---- ellipsoid_query_gpu.cu:58-298 jacobi_eigenvalue (J. Burkardt's routine, n = 3, float storage): the operand types
+ * are the reference's (C++ overloads on float arguments: sqrt / fabs in float; the literals 10.0, 0.5, 1.0 are double, so
+ * those sub-expressions are evaluated in double and rounded on assignment).  Multiply-adds are NOT contracted here
+ * (the build uses -ffp-contract=off): which of them nvcc fuses is not knowable from the source -- parity unpinned. */
+static void oracle_jacobi3(float a[9], int it_max, float v[9], float d[3]) {
+    const int n = 3;
+    float bw[3], zw[3];
+    for (int j = 0, k = 0; j < n; ++j)
+        for (int i = 0; i < n; ++i) v[k++] = i == j ? 1.0f : 0.0f;
+    for (int i = 0; i < n; ++i) { d[i] = a[i + i * n]; bw[i] = d[i]; zw[i] = 0.0f; }
+    int it_num = 0;
+    while (it_num < it_max) {
+        ++it_num;
+        float thresh = 0.0f;
+        for (int j = 0; j < n; ++j)
+            for (int i = 0; i < j; ++i) thresh = thresh + a[i + j * n] * a[i + j * n];
+        thresh = sqrtf(thresh) / (float)(4 * n);
+        if (thresh == 0.0f) break;
+        for (int p = 0; p < n; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const float gapq = (float)(10.0 * (double)fabsf(a[p + q * n]));
+                const float termp = gapq + fabsf(d[p]);
+                const float termq = gapq + fabsf(d[q]);
+                if (4 < it_num && termp == fabsf(d[p]) && termq == fabsf(d[q])) {
+                    a[p + q * n] = 0.0f;
+                } else if (thresh <= fabsf(a[p + q * n])) {
+                    float h = d[q] - d[p];
+                    const float term = fabsf(h) + gapq;
+                    float t;
+                    if (term == fabsf(h)) {
+                        t = a[p + q * n] / h;
+                    } else {
+                        const float theta = (float)(0.5 * (double)h / (double)a[p + q * n]);
+                        t = (float)(1.0 / ((double)fabsf(theta) + sqrt(1.0 + (double)(theta * theta))));
+                        if (theta < 0.0f) t = -t;
+                    }
+                    const float c = (float)(1.0 / sqrt(1.0 + (double)(t * t)));
+                    const float s = t * c;
+                    const float tau = (float)((double)s / (1.0 + (double)c));
+                    h = t * a[p + q * n];
+                    zw[p] = zw[p] - h; zw[q] = zw[q] + h;
+                    d[p] = d[p] - h; d[q] = d[q] + h;
+                    a[p + q * n] = 0.0f;
+                    for (int j = 0; j < p; ++j) {
+                        const float g = a[j + p * n]; h = a[j + q * n];
+                        a[j + p * n] = g - s * (h + g * tau);
+                        a[j + q * n] = h + s * (g - h * tau);
+                    }
+                    for (int j = p + 1; j < q; ++j) {
+                        const float g = a[p + j * n]; h = a[j + q * n];
+                        a[p + j * n] = g - s * (h + g * tau);
+                        a[j + q * n] = h + s * (g - h * tau);
+                    }
+                    for (int j = q + 1; j < n; ++j) {
+                        const float g = a[p + j * n]; h = a[q + j * n];
+                        a[p + j * n] = g - s * (h + g * tau);
+                        a[q + j * n] = h + s * (g - h * tau);
+                    }
+                    for (int j = 0; j < n; ++j) {
+                        const float g = v[j + p * n]; h = v[j + q * n];
+                        v[j + p * n] = g - s * (h + g * tau);
+                        v[j + q * n] = h + s * (g - h * tau);
+                    }
+                }
+            }
+        for (int i = 0; i < n; ++i) { bw[i] = bw[i] + zw[i]; d[i] = bw[i]; zw[i] = 0.0f; }
+    }
+    for (int j = 0; j < n; ++j)
+        for (int i = 0; i < j; ++i) a[i + j * n] = a[j + i * n];
+    for (int k = 0; k < n - 1; ++k) {          /* ascending eigenvalues, eigenvector columns follow */
+        int m = k;
+        for (int l = k + 1; l < n; ++l)
+            if (d[l] < d[m]) m = l;
+        if (m != k) {
+            const float t = d[m]; d[m] = d[k]; d[k] = t;
+            for (int i = 0; i < n; ++i) { const float w = v[i + m * n]; v[i + m * n] = v[i + k * n]; v[i + k * n] = w; }
+        }
+    }
+}
+
+/* ellipsoid_query_gpu.cu:311-498 query_ellipsoid_point_kernel behind ellipsoid_query (ellipsoid_query.cpp:13-76: idx and
+ * the per-centre work arrays are zero-filled tensors).  Per centre: (1) the ball query of radius e3 (first nsample hits,
+ * slots pre-filled with the first hit); (2) with >= 3 hits: their covariance about the centre (mean of the hits at least
+ * e1/4 away from it) or about their mean -- skipped (the zero matrix stays) when a hit is exactly the origin; (3) its
+ * eigenvectors by Jacobi rotations; (4) a second pass over all points in the frame of those axes (negated unless the
+ * 'deter' expression equals 1): points with sqrt(x^2/e1^2 + y^2/e2^2 + z^2/e3^2) < 1 that are not listed yet are appended
+ * until nsample.  Returns idx (b, m, nsample). */
+PDA_EXPORT int pda_oracle_ellipsoid_query(int b, int n, int m, float e1, float e2, float e3, int nsample,
+                                          const float *new_xyz_all, const float *xyz_all, int *idx_all) {
+    const float aa = e1 * e1, bb = e2 * e2, cc = e3 * e3;
+#pragma omp parallel for collapse(2) schedule(dynamic, 16)
+    for (int bs = 0; bs < b; ++bs)
+        for (int j = 0; j < m; ++j) {
+            const float *xyz = xyz_all + (size_t)bs * n * 3;
+            const float *nw = new_xyz_all + ((size_t)bs * m + j) * 3;
+            int *idx = idx_all + ((size_t)bs * m + j) * nsample;
+            const float new_x = nw[0], new_y = nw[1], new_z = nw[2];
+            int cnt = 0;
+            for (int k = 0; k < n && cnt < nsample; ++k) {
+                const float d2 = sqdist3(new_x, new_y, new_z, xyz[k * 3 + 0], xyz[k * 3 + 1], xyz[k * 3 + 2]);
+                if (d2 < cc) {
+                    if (cnt == 0)
+                        for (int l = 0; l < nsample; ++l) idx[l] = k;
+                    idx[cnt] = k;
+                    ++cnt;
+                }
+            }
+            const int pts = cnt;
+            if (pts < 3) continue;
+            float cva[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, v[9], dd[3];
+            float *M = (float *)malloc(sizeof(float) * 3 * (size_t)pts);
+            int flag = 0;
+            for (int k = 0; k < pts; ++k) {
+                const int ii = idx[k];
+                M[3 * k + 0] = xyz[ii * 3 + 0]; M[3 * k + 1] = xyz[ii * 3 + 1]; M[3 * k + 2] = xyz[ii * 3 + 2];
+                if (M[3 * k] == 0 && M[3 * k + 1] == 0 && M[3 * k + 2] == 0) flag = 1;
+            }
+            if (!flag) {
+                float means[3] = {0.0f, 0.0f, 0.0f};
+                for (int up = 0; up < pts; ++up) { means[0] += M[up * 3]; means[1] += M[up * 3 + 1]; means[2] += M[up * 3 + 2]; }
+                means[0] = means[0] / (float)pts; means[1] = means[1] / (float)pts; means[2] = means[2] / (float)pts;
+                const float dm = sqrtf((means[0] - new_x) * (means[0] - new_x) + (means[1] - new_y) * (means[1] - new_y) +
+                                       (means[2] - new_z) * (means[2] - new_z));
+                const int about_centre = (double)dm >= (double)e1 / 4.0;
+                for (int up = 0; up < pts; ++up) {
+                    M[3 * up + 0] = M[3 * up + 0] - (about_centre ? new_x : means[0]);
+                    M[3 * up + 1] = M[3 * up + 1] - (about_centre ? new_y : means[1]);
+                    M[3 * up + 2] = M[3 * up + 2] - (about_centre ? new_z : means[2]);
+                }
+                for (int t3 = 0; t3 < 3; ++t3)
+                    for (int tn = 0; tn < 3; ++tn) {
+                        float acc = 0.0f;
+                        for (int n3 = 0; n3 < pts; ++n3) acc += M[t3 + 3 * n3] * M[tn + n3 * 3];
+                        cva[tn + t3 * 3] = acc / (float)(pts - 1);
+                    }
+            }
+            free(M);
+            oracle_jacobi3(cva, 1000, v, dd);
+            const float deter = v[6] * (v[4] * v[2] - v[1] * v[5]) - v[7] * (v[3] * v[2] - v[0] * v[5]) + v[8] * (v[3] * v[1] - v[0] * v[4]);
+            const float sg = deter == 1.0f ? 1.0f : -1.0f;       /* the reference negates every entry of the frame otherwise */
+            cnt = pts;
+            for (int k = 0; k < n; ++k) {
+                if (cnt == nsample) break;
+                const float s0 = xyz[k * 3 + 0] - new_x, s1 = xyz[k * 3 + 1] - new_y, s2 = xyz[k * 3 + 2] - new_z;
+                const float xx = (sg * v[6]) * s0 + (sg * v[7]) * s1 + (sg * v[8]) * s2;
+                const float yy = (sg * v[3]) * s0 + (sg * v[4]) * s1 + (sg * v[5]) * s2;
+                const float zz = (sg * v[0]) * s0 + (sg * v[1]) * s1 + (sg * v[2]) * s2;
+                const float d3 = sqrtf((xx * xx / aa) + (yy * yy / bb) + (zz * zz / cc));
+                if (d3 < 1) {
+                    int kflag = 0;
+                    for (int kk = 0; kk < nsample; ++kk)
+                        if (idx[kk] == k) { kflag = 1; break; }
+                    if (!kflag) { idx[cnt] = k; ++cnt; }
+                }
+            }
+        }
+    return 1;
+}
+
 /* ball_query_gpu.cu:70-117 ball_query_dilated_kernel_fast */
 PDA_EXPORT int pda_oracle_ball_query_dilated(int b, int n, int m, float max_radius,
                                              float min_radius, int nsample,

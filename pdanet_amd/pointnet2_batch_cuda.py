@@ -7,9 +7,9 @@ pointnet2`` unchanged.  Each wrapper validates like the reference's CHECK_INPUT
 (ball_query.cpp:17-29: CUDA tensor + contiguous), launches the HIP kernel on torch's CURRENT
 stream through the C ABI (include/pda_pointnet2.h) and returns what the reference returns
 (1, 2 for the with-dist FPS, None for the interpolate trio).  Where the reference prints and
-calls exit(-1), this raises.  ``ellipsoid_query`` is not reached by PDA-SSD.yaml: the name exists so the
-module's name set equals the reference's, and raises PdaError (PDA_ERR_UNSUPPORTED).  ``chamfer_forward/backward``
- are implemented.
+calls exit(-1), this raises.  ``ellipsoid_query`` is not reached by PDA-SSD.yaml and is implemented all the
+same (csrc/ellipsoid_query.hip), as are ``chamfer_forward/backward``: the module's name set equals the
+reference's and every name has a kernel.
 """
 import ctypes
 
@@ -94,8 +94,8 @@ def debug_fps_spin_limit(polls):
 
 
 def ellipsoid_query(new_xyz, xyz, e1, e2, e3, nsample):
-    """pointnet2_api.cpp:16 / ellipsoid_query.cpp:13: allocates and returns idx (b, m, nsample) in the reference.  Not
-    on the PDA-SSD path and not implemented: pda_ellipsoid_query returns PDA_ERR_UNSUPPORTED and this raises PdaError."""
+    """pointnet2_api.cpp:16 / ellipsoid_query.cpp:13-76: allocates (zero-filled) and returns idx (b, m, nsample): the ball
+    query of radius e3 extended by the points inside the ellipsoid (e1, e2, e3) aligned with the hits' principal axes."""
     b, m, n = new_xyz.shape[0], new_xyz.shape[1], xyz.shape[1]
     idx = torch.zeros((b, m, nsample), dtype=I32, device=new_xyz.device)
     _call("pda_ellipsoid_query", xyz, _chk(new_xyz, "new_xyz", F32), _chk(xyz, "xyz", F32), _chk(idx, "idx", I32),

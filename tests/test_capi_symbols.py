@@ -78,10 +78,11 @@ def test_mirror_module_matches_reference_names():
         assert callable(getattr(ext, name))
 
 
-def test_ellipsoid_query_is_an_explicit_unsupported_entry(lib):
-    """pointnet2_api.cpp:16: the name is part of the boundary; no PDA-SSD yaml reaches it, the C ABI says so."""
-    st = lib.pda_ellipsoid_query(None, None, None, 1, 8, 8, ctypes.c_float(1), ctypes.c_float(2), ctypes.c_float(1), 4, None)
-    assert st == 3 and b"ellipsoid_query" in lib.pda_last_error()
+def test_ellipsoid_query_validates_its_arguments(lib):
+    """pointnet2_api.cpp:16: implemented since round 3 (csrc/ellipsoid_query.hip); bad sizes are refused before any HIP call."""
+    st = lib.pda_ellipsoid_query(None, None, None, 1, 8, 8, ctypes.c_float(1), ctypes.c_float(2), ctypes.c_float(1), 0, None)
+    assert st == 1 and b"pda_ellipsoid_query" in lib.pda_last_error()
+    assert lib.pda_ellipsoid_query(None, None, None, 0, 8, 8, ctypes.c_float(1), ctypes.c_float(2), ctypes.c_float(1), 4, None) == 0
 
 
 def test_ops_refuse_cpu_tensors():

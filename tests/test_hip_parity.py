@@ -503,3 +503,32 @@ def test_random_shapes_indices_exact(ext, oracle):
         d_d = torch.zeros((b, mc, 3), device="cuda"); i_d = torch.zeros((b, mc, 3), dtype=torch.int32, device="cuda")
         ext.three_nn_wrapper(b, mc, n, dev(new_xyz), dev(xyz), d_d, i_d)
         assert np.array_equal(i_o, i_d.cpu().numpy()) and np.array_equal(d_o, d_d.cpu().numpy()), ("three_nn", case)
+
+
+# ---------------------------------------------------------------- ellipsoid_query (pointnet2_api.cpp:16)
+@pytest.mark.parametrize("b,n,m,e,ns,dist", [
+    (2, 2048, 256, (3.0, 0.8, 1.5), 16, "L"),
+    (2, 1024, 128, (1.5, 0.8, 2.0), 16, "L"),         # the ellipsoid lies inside the first ball: rows stay the ball query's
+    (1, 4096, 512, (2.0, 1.0, 1.0), 32, "L"),
+    (2, 700, 90, (6.0, 3.0, 4.0), 64, "U"),          # wide balls: many centres are full after the first query
+    (1, 300, 40, (0.5, 0.5, 0.5), 8, "U"),           # small balls: most centres have < 3 hits and keep their row
+])
+def test_ellipsoid_query_rows_equal_oracle(ext, oracle, b, n, m, e, ns, dist):
+    """csrc/ellipsoid_query.hip against the CPU statement of ellipsoid_query_gpu.cu:311-498 (same float expressions on
+    both sides): rows bit-exact.  A hit at the exact origin (the reference's `flag`) is planted in scene 0."""
+    xyz = cloud(b, n, seed=31 + ns, dist=dist)
+    rng = np.random.default_rng(ns)
+    new_xyz = np.ascontiguousarray(xyz[:, rng.permutation(n)[:m]])
+    xyz[0, 5] = 0.0
+    new_xyz[0, 0] = (0.1, 0.0, 0.05)                 # a centre next to the origin point
+    exp = oracle.ellipsoid_query(new_xyz, xyz, e[0], e[1], e[2], ns)
+    got = ext.ellipsoid_query(dev(new_xyz), dev(xyz), e[0], e[1], e[2], ns)
+    torch.cuda.synchronize()
+    assert np.array_equal(exp, got.cpu().numpy())
+    # the second pass did something: some row differs from the plain ball query of radius e3
+    plain = np.zeros((b, m, ns), np.int32)
+    oracle.ball_query_wrapper(b, n, m, e[2], ns, new_xyz, xyz, plain)
+    if max(e[0], e[1]) > e[2] and ns >= 16:
+        assert (plain != exp).any()
+    if max(e[0], e[1]) <= e[2]:
+        assert np.array_equal(plain, exp)

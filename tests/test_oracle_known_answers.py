@@ -263,3 +263,19 @@ def test_ball_query_non_finite_point_is_never_a_hit(oracle):
     idx = np.zeros((1, 1, 4), np.int32)
     oracle.ball_query_wrapper(1, 4, 1, 1.0, 4, new_xyz, xyz, idx)
     assert idx.tolist() == [[[0, 2, 0, 0]]]
+
+
+def test_ellipsoid_query_extends_the_ball_along_the_principal_axis(oracle):
+    """ellipsoid_query_gpu.cu:311-498 by hand: hits on a line along x -> the covariance's largest eigenvector is x, which
+    the second pass scales by e1 (rspoint[0] uses the LAST eigenvector column, :455-457).  With (e1, e2, e3) = (3, 0.5, 1):
+    the first query (radius e3 = 1) finds points 0..3; the point at x = 2.5 lies inside the re-oriented ellipsoid and is
+    appended, the points at y = 0.8 and z = 0.8 (inside the ball of radius 1? no: listed already if so) are not new, the
+    point at y = 2.5 stays outside.  A centre with fewer than 3 hits keeps the plain ball-query row."""
+    xyz = np.array([[[0.1, 0, 0], [0.4, 0, 0], [-0.3, 0, 0], [0.7, 0, 0],      # 0..3: on the x axis, inside radius 1
+                     [2.5, 0, 0],                                             # 4: outside the ball, inside the ellipsoid along x
+                     [0, 2.5, 0],                                             # 5: same distance along y: outside (e2 = 0.5)
+                     [50, 50, 50], [50.2, 50, 50]]], np.float32)             # 6, 7: a far pair for the second centre
+    new_xyz = np.array([[[0.05, 0.0, 0.0], [50.1, 50, 50]]], np.float32)
+    idx = oracle.ellipsoid_query(new_xyz, xyz, 3.0, 0.5, 1.0, 8)
+    assert idx[0, 0].tolist() == [0, 1, 2, 3, 4, 0, 0, 0]
+    assert idx[0, 1].tolist() == [6, 7, 6, 6, 6, 6, 6, 6]                    # 2 hits: no second pass
