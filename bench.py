@@ -21,11 +21,12 @@ Workloads (--workload; default detector_train):
   backbone           backbone forward+backward with a synthetic loss (round 1's headline; now under `extra`).
   backbone_infer     backbone forward, eval BN, fused SA kernel (BASELINE configs[1]).
   kitti_detector_train_bf16   detector_train on the KITTI yaml in dense-bf16 mode (BASELINE configs[2]; --batch 4).
+  kitti_detector_train        the same iteration in the default mode (f32 tensors, split-bf16 contractions, unique tokens).
   train_step, kitti_train_bf16, backbone_bf16, backbone_infer_bf16   see benchmarks/workloads.py.
   sampling_grouping  only the sampling/grouping operators at the ONCE-16k layer shapes.
 
-The default run (N = 1) also times `backbone`, `backbone_infer` and `kitti_detector_train_bf16 --batch 4` for a
-few steps each and reports them under "extra" (--no-extra skips that).
+The default run (N = 1) also times `backbone`, `backbone_infer`, `kitti_detector_train_bf16 --batch 4` and
+`kitti_detector_train --batch 4` for a few steps each and reports them under "extra" (--no-extra skips that).
 """
 import argparse
 import json
@@ -198,7 +199,10 @@ def main():
         # secondary timings (few steps each): round 1's headline and BASELINE configs[1] / configs[2]
         del wl
         extra = {}
-        for xname, xbatch in (("backbone", 2), ("backbone_infer", 2), ("kitti_detector_train_bf16", 4)):
+        # configs[2] (KITTI, B = 4, whole iteration) in both of this repo's forms: dense-bf16 mode (bf16 tensors between the
+        # GEMMs, dense encoder) and the default mode (f32 tensors, every large contraction as a 3-term bf16 split on the bf16
+        # matrix cores, unique-token encoder)
+        for xname, xbatch in (("backbone", 2), ("backbone_infer", 2), ("kitti_detector_train_bf16", 4), ("kitti_detector_train", 4)):
             torch.cuda.empty_cache()
             xw = workloads.create(xname, xbatch, args.points, device, rank, world)
             xsteps = max(5, min(args.steps, 10))

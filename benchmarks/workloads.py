@@ -647,6 +647,8 @@ def create(name, batch, n_points, device, rank, world):
     if name == "kitti_detector_train_bf16":
         return DetectorTrainWorkload(batch, n_points, device, rank, world, dense_bf16=True, cfg="kitti_pda_ssd.yaml",
                                      dataset="kitti")
+    if name == "kitti_detector_train":       # the same iteration in the default f32 mode (unique-token encoder, split-bf16 GEMMs)
+        return DetectorTrainWorkload(batch, n_points, device, rank, world, dense_bf16=False, cfg="kitti_pda_ssd.yaml", dataset="kitti")
     if name == "train_step":
         return TrainStepWorkload(batch, n_points, device, rank, world)
     if name == "kitti_train_bf16":
