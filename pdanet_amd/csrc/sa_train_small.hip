@@ -35,7 +35,6 @@ namespace pda {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int SS_WAVES = 8;                         // waves per workgroup: two per SIMD -- one wave's VALU / memory work runs under the other's MFMA chain
-constexpr int SS_WAVES_HEAVY = 4;                   // the one pass whose working set needs more than 256 registers (B3 at c3 = 64)
 constexpr int SS_LD = 33;                           // row stride (floats) of the transposed tiles
 constexpr int SS_LDS_WAVE = 96 * SS_LD;             // per wave: a 64-row block + a 32-row block
 constexpr int SS_LDS_WPACK = 6400;                   // LDS (floats): [packed weights | state | per-wave tiles]
@@ -131,6 +130,31 @@ __device__ __forceinline__ void ss_mm(f32x16 (&acc)[R], const HinT& hin, const S
                 acc[r] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b, acc[r], 0, 0, 0);
             }
         }
+}
+
+// one output row block rb of W x Hin (the fragments of block rb only)
+template <int KS, int R, typename HinT>
+__device__ __forceinline__ void ss_mm_block(f32x16& acc, const HinT& hin, const SsFrag<KS, R>& w, int rb) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+    for (int tq = 0; tq < KS / 4; ++tq) {
+        const float4 a4 = w.f(tq, rb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w)), hin(tq * 4 + e), acc, 0, 0, 0);
+    }
+}
+// acc += W[:, k-steps 16 kb .. 16 kb + 15] x (one 32-row accumulator block): a slice of a longer contraction, in its order
+template <int KS, typename HinT>
+__device__ __forceinline__ void ss_mm_slice(f32x16& acc, const HinT& hin, const SsFrag<KS, 1>& w, int kb) {
+#pragma unroll
+    for (int tq = 0; tq < 4; ++tq) {
+        const float4 a4 = w.f(4 * kb + tq, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(e == 0 ? a4.x : (e == 1 ? a4.y : (e == 2 ? a4.z : a4.w)), hin(tq * 4 + e), acc, 0, 0, 0);
+    }
 }
 
 struct SsX0 {
@@ -471,7 +495,7 @@ __global__ __launch_bounds__(W * 64) void ss_bwd_kernel(const SsParams p) {
             for (int q = 0; q < 4; ++q)
                 gin[0][q] = 8 * q + 4 * h < cup ? *reinterpret_cast<const float4*>(row + 8 * q + 4 * h) : make_float4(0, 0, 0, 0);
         }
-        f32x16 a1[1], xh1, a2[1], xh2, a3[R3], d[1];
+        f32x16 a1[1], xh1, a2[1], xh2, d[1];
         ss_mm<4, 1>(a1, SsX0{x0}, w1);
         ss_bn_relu<true>(a1[0], xh1, st1, 32, 0, h);                  // a1 = y1
         if (STAGE >= 2) {
@@ -479,14 +503,19 @@ __global__ __launch_bounds__(W * 64) void ss_bwd_kernel(const SsParams p) {
             ss_bn_relu<true>(a2[0], xh2, st2, 32, 0, h);              // a2 = y2
         }
         if constexpr (STAGE == 3) {
-            ss_mm<16, R3>(a3, SsAcc<1>{a2}, w3);
-            // dz3 = gamma3 invstd3 (dyh - mean(dyh) - xh3 mean(dyh xh3)), dyh = the pooled gradient at the arg-max slot
+            // one 32-channel block of layer 3 at a time (registers: the pass fits two waves per SIMD this way); the order of
+            // every sum is that of the whole-width form
             const int slot = j & (NS - 1);
 #pragma unroll
-            for (int rb = 0; rb < R3; ++rb)
+            for (int i = 0; i < 16; ++i) d[0][i] = 0.f;
+            ss_to_lds(yt, a2[0], 0, lane);
+#pragma unroll
+            for (int rb = 0; rb < R3; ++rb) {
+                f32x16 zb[1];
+                ss_mm_block<16, R3>(zb[0], SsAcc<1>{a2}, w3, rb);
+                // dz3 = gamma3 invstd3 (dyh - mean(dyh) - xh3 mean(dyh xh3)), dyh = the pooled gradient at the arg-max slot
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    asm volatile("" ::: "memory");     // one (rb, q) group of loads at a time: registers
                     const SsChan c = ss_chan(st3, 32 * R3, rb, q, h);
                     const float4 m1 = *reinterpret_cast<const float4*>(st3 + 4 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
                     const float4 m2 = *reinterpret_cast<const float4*>(st3 + 5 * 32 * R3 + rb * 32 + 8 * q + 4 * h);
@@ -495,17 +524,19 @@ __global__ __launch_bounds__(W * 64) void ss_bwd_kernel(const SsParams p) {
                     const int av[4] = {ar.x, ar.y, ar.z, ar.w};
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float xh = (a3[rb][4 * q + e] - f4(c.mu, e)) * f4(c.is, e);
+                        const float xh = (zb[0][4 * q + e] - f4(c.mu, e)) * f4(c.is, e);
                         const float dyh = (av[e] == slot && xh * f4(c.ga, e) + f4(c.be, e) > 0.f) ? f4(go, e) : 0.f;
-                        a3[rb][4 * q + e] = f4(c.ga, e) * f4(c.is, e) * (dyh - (f4(m1, e) + xh * f4(m2, e)));
+                        zb[0][4 * q + e] = f4(c.ga, e) * f4(c.is, e) * (dyh - (f4(m1, e) + xh * f4(m2, e)));
                     }
                 }
-#pragma unroll
-            for (int rb = 0; rb < R3; ++rb) ss_to_lds(zt, a3[rb], rb, lane);
-            ss_to_lds(yt, a2[0], 0, lane);
-            ss_wave_fence();
-            ss_dw_tile<R3>(dw, zt, yt, lane);                          // dW3 += dz3 y2^T
-            ss_mm<16 * R3, 1>(d, SsAcc<R3>{a3}, w3t);                  // dy2 = W3^T dz3
+                ss_to_lds(zt, zb[0], 0, lane);
+                ss_wave_fence();
+                f32x16 dwb[1] = {dw[rb]};
+                ss_dw_tile<1>(dwb, zt, yt, lane);                      // dW3[block rb] += dz3 y2^T
+                dw[rb] = dwb[0];
+                ss_mm_slice<16 * R3>(d[0], SsAcc<1>{zb}, w3t, rb);     // dy2 += W3^T[:, block rb] dz3
+                ss_wave_fence();                                       // zt is rewritten by the next block
+            }
         } else {
             // the gradient this pass starts from: dz' (tokens, cup), already masked by its ReLU
             f32x16 dzp;
@@ -666,7 +697,7 @@ static bool ss_launch_fwd(int stage, const SsParams& p, hipStream_t s, int& bloc
 }
 template <int R3, int NS, int STAGE>
 static bool ss_launch_bwd_stage(const SsParams& p, hipStream_t s, int& blocks) {
-    constexpr int W = (STAGE == 3 && R3 == 2) ? SS_WAVES_HEAVY : SS_WAVES;
+    constexpr int W = SS_WAVES;
     static PerDevice<bool> once;
     constexpr int bytes = ss_lds_floats(W) * (int)sizeof(float);
     if (!ss_lds_ok(ss_bwd_kernel<R3, NS, STAGE, W>, once, bytes)) return false;

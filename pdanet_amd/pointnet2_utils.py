@@ -564,12 +564,15 @@ def _split_gemm_ok(x2d, k):
             and not DENSE_BF16 and not torch.is_autocast_enabled())
 
 
+ROWS_IN_REGISTERS_MAX_TOKENS = int(os.environ.get("PDA_ROWS_MAX_TOKENS", "98304"))
+
+
 def _rows_in_registers(tokens, k, n_out):
     """Which split-bf16 kernel a (tokens, k) x (n_out, k)^T product takes: lin_split_kernel (a wave's rows stay in registers:
     short K only) is ahead of the 256 x 256 tiles of gemm_split_wide_kernel while those leave a ragged last round of
     workgroups on the 256 CUs; from ~100k tokens the tiles win (131072 x 256 -> 256: 0.109 against 0.131 ms, -> 512: 0.217
     against 0.233; 65536 x 256 -> 512: level; 32307 x 256 -> 768: 0.077 against 0.101 for the rows form)."""
-    return k <= 256 and n_out % 128 == 0 and n_out <= 2048 and tokens < 98304
+    return k <= 256 and n_out % 128 == 0 and n_out <= 2048 and tokens < ROWS_IN_REGISTERS_MAX_TOKENS
 
 
 # Packed bf16 planes of the PARAMETER weights, keyed on the storage address: {ptr: (tag, planes of W, planes of W^T, weak
