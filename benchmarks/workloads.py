@@ -190,9 +190,20 @@ class KernelTimers:
             "kernel": "lin_cols_kernel / sa_gather_linear (v_mfma_f32_32x32x2_f32)", "launches_per_step": nf // steps,
             "achieved": ff / tf / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": ff / tf / 1e12 / F32_MFMA_PEAK_TF,
             "ms_per_step": tf / steps * 1e3, "gflop_per_step": ff / steps / 1e9}
-        if ns_ == 0:            # PDA_SPLIT_GEMM=0: everything on the f32-input MFMA
+        tr, fr, nr = part("f32_recompute")
+        small = None if nr == 0 else {
+            "kernel": "ss_fwd_kernel / ss_bwd_kernel (csrc/sa_train_small.hip: SA layer 0 as recompute passes, v_mfma_f32_32x32x2_f32)",
+            "calls_per_step": nr // steps, "achieved": fr / tr / 1e12, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": fr / tr / 1e12 / F32_MFMA_PEAK_TF, "ms_per_step": tr / steps * 1e3, "gflop_per_step": fr / steps / 1e9,
+            "note": "ALGORITHMIC flops (one forward and one backward evaluation of the chain per token) / time of all passes incl. "
+                    "their finalize launches; the passes issue ~2.6x (forward) and ~3x (backward) that on the matrix cores -- "
+                    "recomputing a token from its 16-byte input instead of moving 0.4-1 KB of activations per token through HBM"}
+        if ns_ == 0:            # PDA_SPLIT_GEMM=0 / dense-bf16 mode: no split-bf16 launch among the SA group MLPs
+            if f32_part is None:
+                return None if small is None else dict(small, bound="mfma", traffic=None)
             util = pmc_record("mfma_util", "pda::lin_cols_kernel", ["sa_mlp.hip"], prefix=True, by="avg_ns")
             out = dict(f32_part, bound="mfma", traffic=None, mfma_busy_pmc=None if util is None else round(util["mfma_util"], 4),
+                       layer0_recompute_part=small,
                        note="v_mfma_f32_32x32x2_f32; launches include the weight-packing kernel in front of each contraction")
             out["kernel"] += " (SA group MLP, training form: forward + input gradient)"
             return out
@@ -205,6 +216,7 @@ class KernelTimers:
                 "achieved_f32_equiv": fs / ts / 1e12, "peak_f32_input_mfma": F32_MFMA_PEAK_TF,
                 "traffic": None, "ms_per_step": ts / steps * 1e3, "gflop_per_step": fs / steps / 1e9,
                 "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4), "f32_mfma_part": f32_part,
+                "layer0_recompute_part": small,
                 "note": "f32 contractions on v_mfma_f32_32x32x16_bf16 with every operand split into three bf16 terms (x = h + m + l "
                         "exactly; 6 of 9 products kept, error at the f32 fmaf chain's: tests/test_gemm_split.py).  achieved = "
                         "6 x algorithmic flops / time = the bf16 MFMA work really issued, peak = dense bf16 MFMA; "

@@ -1085,11 +1085,12 @@ class SaSmallChainTrain(Function):
         zmax = torch.empty((B, M, c3), dtype=torch.float32, device=dev)
         arg = torch.empty((B, M, c3), dtype=torch.uint8, device=dev)
         track = [bn.track_running_stats for bn in bns]
-        pointnet2.sa_small_train_fwd(xyz, new_xyz, feats_pm, idx, (w1.contiguous(), w2.contiguous(), w3.contiguous()),
-                                     (g1, g2, g3), (b1, b2, b3),
-                                     [bn.running_mean if t else None for bn, t in zip(bns, track)],
-                                     [bn.running_var if t else None for bn, t in zip(bns, track)],
-                                     [bn.eps for bn in bns], [bn.momentum for bn in bns], ws, out, zmax, arg, B, N, M, c, ns)
+        macs = w1.numel() + w2.numel() + w3.numel()            # algorithmic: one pass over the chain per token
+        _sa_timed(2.0 * B * M * ns * macs, lambda: pointnet2.sa_small_train_fwd(
+            xyz, new_xyz, feats_pm, idx, (w1.contiguous(), w2.contiguous(), w3.contiguous()), (g1, g2, g3), (b1, b2, b3),
+            [bn.running_mean if t else None for bn, t in zip(bns, track)],
+            [bn.running_var if t else None for bn, t in zip(bns, track)],
+            [bn.eps for bn in bns], [bn.momentum for bn in bns], ws, out, zmax, arg, B, N, M, c, ns), "f32_recompute")
         ctx.save_for_backward(xyz, new_xyz, feats_pm, idx, zmax, arg, ws, w1, w2, w3)
         ctx.dims = (B, N, M, c, ns)
         return out
@@ -1105,8 +1106,10 @@ class SaSmallChainTrain(Function):
         dws = [torch.empty(w.shape, dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
         dgs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
         dbs = [torch.empty((w.shape[0],), dtype=torch.float32, device=dev) for w in (w1, w2, w3)]
-        pointnet2.sa_small_train_bwd(xyz, new_xyz, feats_pm, idx, grad_out.contiguous().float(), zmax, arg, ws, dz2, dz1, dws, dgs, dbs,
-                                     B, N, M, c, ns)
+        gout = grad_out.contiguous().float()
+        macs = w1.numel() + w2.numel() + w3.numel()            # algorithmic backward: weight gradients + input gradients of layers 2, 3
+        _sa_timed(2.0 * tokens * (2 * macs - w1.numel()), lambda: pointnet2.sa_small_train_bwd(
+            xyz, new_xyz, feats_pm, idx, gout, zmax, arg, ws, dz2, dz1, dws, dgs, dbs, B, N, M, c, ns), "f32_recompute")
         return (None, None, None, None, dws[0], dws[1], dws[2], dgs[0], dbs[0], dgs[1], dbs[1], dgs[2], dbs[2], None)
 
 

@@ -19,7 +19,7 @@ for t in fps ball_query wgrad; do
     run fetch_size_$t FETCH_SIZE $t
     run write_size_$t WRITE_SIZE $t
 done
-for t in wgrad sa_mlp lin_cols lin_split gemm_split; do
+for t in wgrad sa_mlp lin_cols lin_split gemm_split sa_small; do
     run mfma_busy_$t SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE $t
 done
 python3 tools/pmc_summarize.py "$DST"

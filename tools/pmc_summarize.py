@@ -47,12 +47,12 @@ json.dump(traffic, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 util = {"_how": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python3 tools/pmc_targets.py <target> 5.  "
                 "mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 * 1024): busy SIMD-cycles over kernel cycles x 1024 SIMDs "
                 "(GRBM_GUI_ACTIVE is summed over the 8 XCDs); clock_ghz = GRBM_GUI_ACTIVE / 8 / kernel duration.",
-        "csrc_sha1": {f: sha(f) for f in ("wgrad.hip", "sa_mlp.hip", "gemm_split.hip")}, "kernels": {}}
-for target in ("wgrad", "sa_mlp", "lin_cols", "lin_split", "gemm_split"):
+        "csrc_sha1": {f: sha(f) for f in ("wgrad.hip", "sa_mlp.hip", "gemm_split.hip", "sa_train_small.hip")}, "kernels": {}}
+for target in ("wgrad", "sa_mlp", "lin_cols", "lin_split", "gemm_split", "sa_small"):
     agg = collections.OrderedDict()
     for x in rows(os.path.join(dst, "mfma_busy_%s.csv" % target)):
         name = x["Kernel_Name"]
-        if not any(k in name for k in ("wgrad_kernel", "wgrad_split_kernel", "sa_mlp_kernel", "lin_cols_kernel", "lin_split_kernel", "gemm_split_wide_kernel", "gemm_split_kernel")):
+        if not any(k in name for k in ("wgrad_kernel", "wgrad_split_kernel", "sa_mlp_kernel", "lin_cols_kernel", "lin_split_kernel", "gemm_split_wide_kernel", "gemm_split_kernel", "ss_fwd_kernel", "ss_bwd_kernel")):
             continue
         key = "%s grid=%s" % (name.split("(")[0].replace("void ", ""), x["Grid_Size"])
         d = agg.setdefault(key, {"n": collections.Counter(), "v": collections.Counter(), "ns": 0.0})

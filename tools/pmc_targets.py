@@ -8,6 +8,7 @@
   lin_cols     training-form contraction 512->512, 131072 tokens -> mfma_util["pda::lin_cols_kernel ..."]
   lin_split    the same contraction on the split-bf16 kernel     -> mfma_util["pda::lin_split_kernel ..."]
   gemm_split   the same on the LDS-tiled split-bf16 kernel       -> mfma_util["pda::gemm_split_wide_kernel ..."]
+  sa_small     ONCE layer 0, scale 2, training passes             -> mfma_util["pda::ss_fwd_kernel / ss_bwd_kernel ..."]
 Inputs are the bench's (synth scene config_id 2, distribution L)."""
 import sys
 
@@ -65,6 +66,16 @@ elif target == "lin_split":
     wf = ext.linear_split_pack(w, n, k)
     for _ in range(reps):
         ext.linear_split(x, wf, None, y, t, k, n)
+elif target == "sa_small":
+    # the narrow SA scale in training form (csrc/sa_train_small.hip): ONCE layer 0, scale 2 (4 -> 32 -> 32 -> 64, 32 neighbours,
+    # 2 x 16384 centres = 1 M tokens), forward + backward passes
+    import torch.nn as nn
+    mlp = nn.Sequential(*[m for k in range(3) for m in (nn.Conv2d((4, 32, 32)[k], (32, 32, 64)[k], 1, bias=False), nn.BatchNorm2d((32, 32, 64)[k]), nn.ReLU())]).to(dev).train()
+    feats = torch.rand(2, 16384, 1, device=dev)
+    idx = pu.ball_query(0.8, 32, xyz, xyz)
+    for _ in range(reps):
+        out = pu.sa_small_chain_train(xyz, xyz, feats, idx, mlp)
+        out.backward(torch.ones_like(out))
 else:
     raise SystemExit("unknown target " + target)
 torch.cuda.synchronize()
