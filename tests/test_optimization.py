@@ -67,8 +67,11 @@ def test_onecycle_schedule_matches_reference(gold):
 def test_cpu_parameters_are_rejected(gold):
     from pdanet_amd import optimization as opt
     from pdanet_amd._lib import PdaError
-    with pytest.raises(PdaError):
-        opt.FlatAdamOneCycle(_model(gold, "cpu"), wd=0.01)
+    # the flat buffers are plumbing and may be built anywhere (the gloo tests exchange gradients on the CPU); the update
+    # itself is csrc/optim.hip and nothing else
+    o = opt.FlatAdamOneCycle(_model(gold, "cpu"), wd=0.01)
+    with pytest.raises(PdaError, match="no CPU path"):
+        o.step()
 
 
 @pytest.mark.gpu
