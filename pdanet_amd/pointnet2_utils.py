@@ -600,8 +600,8 @@ def _split_planes(w, transposed=False):
     def pack(t):
         src = wd if wd.is_contiguous() else wd.contiguous()
         return pointnet2.linear_split_pack(src, k, n_out, transposed_source=True) if t else pointnet2.linear_split_pack(src, n_out, k)
-    if not wd.is_contiguous():
-        return pack(transposed)
+    if not wd.is_contiguous() or torch.cuda.is_current_stream_capturing():
+        return pack(transposed)      # under capture the packing belongs INSIDE the graph: a replay must see the new weights
     key, tag = wd.data_ptr(), (wd._version, _lib.WEIGHT_EPOCH[0], n_out, k)
     ent = _PACKED_PLANES.get(key)
     if ent is not None:

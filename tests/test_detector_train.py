@@ -331,3 +331,22 @@ def test_headline_size_model_forward_against_the_oracle(mode, oracle):
         exp = np.zeros((B, 4096, g.nsample), np.int32)
         oracle.ball_query_wrapper(B, N, 4096, g.radius, g.nsample, centres_o, xyz_np, exp)
         assert np.array_equal(exp, got.cpu().numpy()), g.radius
+
+
+@pytest.mark.parametrize("segment", ["head", "tail"])
+def test_graph_replay_uses_the_current_weights_f32(segment):
+    """Default (f32) mode: the packed bf16 planes of the split GEMMs are cached per parameter; inside a captured region the
+    packing must be part of the graph, or a replay would keep computing with the weights of capture time.  Four graphed
+    iterations (three optimizer steps behind the capture), then the same batch forward through the replay and through the
+    eager path on the SAME weights: equal losses (a stale weight set is ~3 Adam steps off: orders of magnitude more)."""
+    model, opt, sched, bd = _setup("once_pda_ssd.yaml", "once")
+    setattr(model, "graph_" + segment, True)
+    for it in range(4):
+        _iteration(model, opt, sched, bd, it)
+        opt.step()
+    batch = bd()
+    with torch.enable_grad():
+        loss_g = float(model(batch)[0]['loss'].detach())
+    setattr(model, "graph_" + segment, False)
+    loss_e = float(model(bd())[0]['loss'].detach())
+    assert np.isfinite(loss_g) and loss_g == pytest.approx(loss_e, rel=2e-5)

@@ -4,7 +4,7 @@ import sys, time, torch
 sys.path.insert(0, '.')
 from benchmarks import workloads as bw
 dev = torch.device('cuda:0')
-for name, batch in (('kitti_detector_train_bf16', 4), ('detector_train', 2)):
+for name, batch in (('kitti_detector_train_bf16', 4), ('kitti_detector_train', 4), ('detector_train', 2)):
     wl = bw.create(name, batch, 16384, dev, 0, 1); wl.begin()
     losses = []
     t = time.perf_counter()
