@@ -126,6 +126,11 @@ def main():
               "run" % (args.gpus, env_world), file=sys.stderr)
         sys.exit(2)
 
+    if env_world is not None and env_world > 1:
+        # graph capture (head / tail replayed as hipGraphs) next to a live process group: the watchdog's asynchronous error
+        # handling polls collective events from another thread (torch's CUDA-graphs notes ask for this with captures)
+        os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+        os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
     import torch
     import torch.distributed as dist
     from benchmarks import workloads

@@ -9,6 +9,19 @@ from .backbone import IASSD_Backbone
 from .iassd_head import IASSD_Head
 
 
+def _quiesce_collectives():
+    """Data-parallel runs: the gradient exchange is outside every captured region, but the process group's watchdog thread
+    polls the events of in-flight collectives (cudaEventQuery), and a query from another thread while this thread captures in
+    the default (global) mode invalidates the capture.  The host runs ahead of the device, so the previous iteration's
+    all-reduce may still be in flight when a capture starts at a later iteration (graph_tail chosen by the probe): drain the
+    device and give the watchdog one polling period to retire the finished work.  Once per capture."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and torch.cuda.is_available():
+        import time
+        torch.cuda.synchronize()
+        time.sleep(0.3)
+
+
 class _HeadLoss(nn.Module):
     """IASSD_Head.forward + get_loss (training) as a function of TENSORS only: the form torch.cuda.make_graphed_callables
     captures.  Argument order: centers_features, centers, centers_origin, ctr_offsets, gt_boxes, then the non-empty
@@ -112,6 +125,7 @@ class IASSD(nn.Module):
     @staticmethod
     def _capture(fn, args):
         sample = tuple(a.detach().clone().requires_grad_(a.requires_grad) for a in args)
+        _quiesce_collectives()
         # make_graphed_callables runs warm-up iterations + the capture pass on the sample batch: the BatchNorm running
         # statistics and counters of the captured layers would move several times on one batch.  Snapshot and restore
         # them, so a run with graphs starts from the same buffers as the eager run (replays then update the statistics in

@@ -151,7 +151,16 @@ class FlatAdamOneCycle:
         if not dist.is_initialized() or dist.get_world_size(group) == 1:
             return self
         self._dp_group, self._dp_world = group, dist.get_world_size(group)
-        self._dp_avg = dist.get_backend(group) == "nccl"
+        self._dp_avg = False
+        if dist.get_backend(group) == "nccl":
+            # RCCL averages inside the collective (ncclAvg); probed once on a scratch value so that a build without it
+            # falls back to SUM + scale on every rank alike instead of failing in the first step
+            try:
+                probe = torch.ones(4, device=self.flat_g.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=group)
+                self._dp_avg = bool((probe == 1).all().item())
+            except (RuntimeError, ValueError):
+                self._dp_avg = False
         if sync_parameters:
             src = dist.get_global_rank(group, 0) if group is not None else 0
             dist.broadcast(self.flat_p, src, group=group)

@@ -25,6 +25,17 @@ if layer == 0:
     xyz = pts[:, 1:4].reshape(B, -1, 3).contiguous()
     feats = pts[:, 4:].reshape(B, -1, 1).permute(0, 2, 1).contiguous()
     args = dict(xyz=xyz, features=feats)
+elif layer in (1, 2):
+    # PDA layers: layer 1 (16384 pts, 64 ch, D-FPS -> 4096), layer 2 (4096 pts, 128 ch, ctr-aware top-k -> 2048)
+    n_in, c_in = (16384, 64) if layer == 1 else (4096, 128)
+    xyz = torch.from_numpy(synth.batch_xyz(B, 16384, config_id=2, dist="L")).cuda()
+    if layer == 2:      # the D-FPS picks of layer 1 as input points
+        from pdanet_amd import pointnet2_utils as pu
+        idx = pu.furthest_point_sample(xyz, 4096)
+        xyz = pu.gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    feats = torch.randn(B, c_in, n_in, generator=g).cuda().requires_grad_(True)
+    cls = torch.randn(B, n_in, 5, generator=g).cuda()
+    args = dict(xyz=xyz, features=feats, cls_features=cls)
 else:
     xyz = torch.from_numpy(synth.batch_xyz(B, 2048, config_id=2, dist="L")).cuda()
     feats = torch.randn(B, 256, 2048, generator=g).cuda().requires_grad_(True)
