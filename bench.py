@@ -131,6 +131,9 @@ def main():
         # handling polls collective events from another thread (torch's CUDA-graphs notes ask for this with captures)
         os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
         os.environ.setdefault("NCCL_ASYNC_ERROR_HANDLING", "0")
+    if os.environ.get("PDA_DUMP_STACKS_AFTER"):      # debugging aid: every thread's Python stack after N seconds (a hung rank)
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["PDA_DUMP_STACKS_AFTER"]), exit=False)
     import torch
     import torch.distributed as dist
     from benchmarks import workloads

@@ -43,6 +43,28 @@ def test_gpus_n_spawns_n_ranks_before_touching_the_gpu(monkeypatch):
         assert sys.modules["torch"].cuda.is_initialized() == had_cuda_init
 
 
+def _run_bench(env, argv, limit=150, attempts=2):
+    """bench.py in its own session, killed as a process group at `limit` seconds (torch.distributed.run's workers are
+    grandchildren).  One of ~25 two-rank one-card rehearsals of round 3 stopped making progress for minutes and was never
+    reproduced; the stacks of every thread are dumped before the kill (PDA_DUMP_STACKS_AFTER) and the
+    run is repeated once, so a one-off stall is reported in the test output instead of costing the whole suite its time limit."""
+    import signal
+    env = dict(env, PDA_DUMP_STACKS_AFTER=str(limit - 20))
+    last = None
+    for attempt in range(attempts):
+        p = subprocess.Popen([sys.executable, BENCH] + argv, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                             start_new_session=True)
+        try:
+            out, err = p.communicate(timeout=limit)
+            return subprocess.CompletedProcess(p.args, p.returncode, out, err)
+        except subprocess.TimeoutExpired:
+            os.killpg(p.pid, signal.SIGKILL)
+            out, err = p.communicate()
+            last = (out, err)
+            print("bench.py %s: no result after %d s (attempt %d); stderr tail:\n%s" % (argv, limit, attempt + 1, err[-3000:]))
+    raise AssertionError("bench.py stalled %d times; last stderr tail: %s" % (attempts, last[1][-2000:]))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("tail", ["0", "1"])
 def test_two_ranks_on_one_card_report_world_size_2(tail):
@@ -54,8 +76,7 @@ def test_two_ranks_on_one_card_report_world_size_2(tail):
     env.pop("WORLD_SIZE", None)
     env.pop("PDA_GRAPH_HEAD", None)
     env.pop("PDA_DDP", None)
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "4096",
-                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
+    r = _run_bench(env, ["--gpus", "2", "--steps", "3", "--warmup", "1", "--points", "4096", "--no-cpu-baseline", "--no-extra"])
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, r.stdout
@@ -70,8 +91,7 @@ def test_two_ranks_reference_shaped_ddp_path():
     """PDA_DDP=1 keeps the reference's DistributedDataParallel wrapper (tools/train.py:153-154) available: eager head."""
     env = dict(os.environ, PDA_REHEARSE_ONE_GPU="1", PDA_DIST_BACKEND="gloo", PDA_DDP="1", PYTHONFAULTHANDLER="1")
     env.pop("WORLD_SIZE", None)
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "2", "--warmup", "0", "--points", "4096",
-                        "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=600)
+    r = _run_bench(env, ["--gpus", "2", "--steps", "2", "--warmup", "0", "--points", "4096", "--no-cpu-baseline", "--no-extra"])
     assert r.returncode == 0, r.stderr[-4000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and "DistributedDataParallel" in d["config"]["gradient_exchange"]
