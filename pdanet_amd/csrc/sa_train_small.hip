@@ -23,11 +23,16 @@
 // Arithmetic: exact f32 on v_mfma_f32_32x32x2_f32 with the machinery of csrc/sa_mlp.hip -- a wave owns a tile of 32
 // tokens (lane & 31), the 32x32 accumulator of a layer (rows = channels, columns = tokens) IS the B operand of the next
 // layer, forward (W x H) and backward (W^T x dZ) alike, so activations and gradients never leave registers between
-// layers.  All weight fragments of the chain (<= 84 registers) are loaded ONCE per wave and stay resident while the wave
-// walks its tiles.  The weight gradient contracts over tokens: the tile's dZ and Y blocks are transposed through a
-// wave-private LDS image (row stride 33, no barriers) into operand layout.  The arg-max runs on the transposed z3 tile
-// with one lane per (group, channel): strict '>' over the slots in order = lowest slot on ties (ball query pads short
-// lists with repeats of the first neighbour, so ties are the rule).
+// layers.  Execution shape (what the counters asked for, tools/pmc_ss.sh): per tile the MFMA chain (<= 116 instructions),
+// ~1200 VALU instructions of BatchNorm / ReLU / gradient algebra and the LDS transposes are ONE dependent sequence, so a
+// workgroup is 8 waves = two per SIMD and one wave's VALU / memory phases run under the other's MFMA chain.  To fit 256
+// registers per wave the packed weight fragments and the per-channel state (mean, invstd, gamma, beta, backward means) live
+// in LDS, one copy per workgroup (re-read per tile: a compiler barrier keeps them from being hoisted into registers), the
+// gather runs two tiles ahead, and B3 walks the 32-channel blocks of layer 3 one at a time (same summation order).  The
+// weight gradient contracts over tokens: the tile's dZ and Y blocks are transposed through a wave-private LDS image (row
+// stride 33, no barriers) into operand layout.  The arg-max runs on the transposed z3 tile with one lane per (group,
+// channel): strict '>' over the slots in order = lowest slot on ties (ball query pads short lists with repeats of the first
+// neighbour, so ties are the rule).
 #include "pda_common.h"
 
 namespace pda {
