@@ -1,66 +1,71 @@
-"""The loss functions PDA-SSD's head is configured with (pcdet/utils/loss_utils.py:75-130
-WeightedClassificationLoss, :133-194 WeightedSmoothL1Loss, :340-363 get_corner_loss_lidar)."""
-import numpy as np
+"""The element-wise losses the PDA-SSD head is configured with, in torch (pcdet/utils/loss_utils.py:75-130
+`WeightedClassificationLoss`, :133-194 `WeightedSmoothL1Loss`, :340-363 `get_corner_loss_lidar`).  On the GPU the training
+path computes these terms inside csrc/head_loss.hip (one launch per term, gradient included); this module is the formulation
+those kernels are checked against (tests/test_iassd_head.py) and what runs when the fused path is switched off."""
+import math
+
 import torch
 import torch.nn as nn
 
 from . import box_utils
 
 
+def _stable_bce_logits(logits, targets):
+    """max(x, 0) - x t + log(1 + exp(-|x|)): sigmoid cross-entropy on logits without overflow (:90-108)."""
+    return logits.clamp(min=0) - logits * targets + torch.log1p(torch.exp(-logits.abs()))
+
+
+def _huber(x, beta):
+    """0.5 x^2 / beta below beta, |x| - 0.5 beta above; plain |x| for a vanishing beta (:157-165)."""
+    a = x.abs()
+    if beta < 1e-5:
+        return a
+    return torch.where(a < beta, 0.5 * a ** 2 / beta, a - 0.5 * beta)
+
+
 class WeightedClassificationLoss(nn.Module):
-    @staticmethod
-    def sigmoid_cross_entropy_with_logits(input, target):
-        return torch.clamp(input, min=0) - input * target + torch.log1p(torch.exp(-torch.abs(input)))
+    sigmoid_cross_entropy_with_logits = staticmethod(_stable_bce_logits)
 
     def forward(self, input, target, weights=None, reduction='none'):
-        loss = self.sigmoid_cross_entropy_with_logits(input, target)
+        loss = _stable_bce_logits(input, target)
         if weights is not None:
-            if weights.dim() == 2 or (weights.dim() == 1 and target.dim() == 2):
-                weights = weights.unsqueeze(-1)
-            assert weights.dim() == loss.dim()
-            loss = weights * loss
-        if reduction == 'sum':
-            loss = loss.sum(dim=-1)
-        elif reduction == 'mean':
-            loss = loss.mean(dim=-1)
-        return loss
+            w = weights.unsqueeze(-1) if weights.dim() == loss.dim() - 1 else weights      # per-anchor weights broadcast over classes
+            assert w.dim() == loss.dim()
+            loss = w * loss
+        if reduction == 'none':
+            return loss
+        return loss.sum(dim=-1) if reduction == 'sum' else loss.mean(dim=-1)
 
 
 class WeightedSmoothL1Loss(nn.Module):
+    smooth_l1_loss = staticmethod(_huber)
+
     def __init__(self, beta=1.0 / 9.0, code_weights=None):
         super().__init__()
         self.beta = beta
-        # the reference keeps a plain .cuda() tensor (:153-155); a non-persistent buffer follows the module
-        self.register_buffer("code_weights", None if code_weights is None else
-                             torch.from_numpy(np.array(code_weights, dtype=np.float32)), persistent=False)
-
-    @staticmethod
-    def smooth_l1_loss(diff, beta):
-        if beta < 1e-5:
-            return torch.abs(diff)
-        n = torch.abs(diff)
-        return torch.where(n < beta, 0.5 * n ** 2 / beta, n - 0.5 * beta)
+        # a non-persistent buffer follows the module across devices (the reference keeps a bare .cuda() tensor, :153-155)
+        self.register_buffer("code_weights", None if code_weights is None else torch.tensor(code_weights, dtype=torch.float32),
+                             persistent=False)
 
     def forward(self, input, target, weights=None):
-        target = torch.where(torch.isnan(target), input, target)
-        diff = input - target
+        """(B, N, C) codes.  A NaN target means "no target for this code": it contributes neither loss nor gradient."""
+        diff = input - torch.where(torch.isnan(target), input, target)
         if self.code_weights is not None:
             diff = diff * self.code_weights.view(1, 1, -1)
-        loss = self.smooth_l1_loss(diff, self.beta)
+        loss = _huber(diff, self.beta)
         if weights is not None:
-            assert weights.shape[0] == loss.shape[0] and weights.shape[1] == loss.shape[1]
+            assert weights.shape[:2] == loss.shape[:2]
             loss = loss * weights.unsqueeze(-1)
         return loss
 
 
 def get_corner_loss_lidar(pred_bbox3d, gt_bbox3d):
-    """loss_utils.py:340-363: (N, 7), (N, 7) -> (N) smooth-L1 (beta 1) of the corner distances, the
-    better of the box and its heading-flipped twin."""
+    """(N, 7), (N, 7) -> (N): Huber(1) of the eight corner distances, per corner the smaller of the distances to the box
+    and to its heading-flipped twin, averaged over the corners (:340-363)."""
     assert pred_bbox3d.shape[0] == gt_bbox3d.shape[0]
-    pred = box_utils.boxes_to_corners_3d(pred_bbox3d)
-    gt = box_utils.boxes_to_corners_3d(gt_bbox3d)
-    flip = gt_bbox3d.clone()
-    flip[:, 6] += np.pi
-    gt_flip = box_utils.boxes_to_corners_3d(flip)
-    dist = torch.min(torch.norm(pred - gt, dim=2), torch.norm(pred - gt_flip, dim=2))
-    return WeightedSmoothL1Loss.smooth_l1_loss(dist, beta=1.0).mean(dim=1)
+    corners = box_utils.boxes_to_corners_3d(pred_bbox3d)
+    twin = gt_bbox3d.clone()
+    twin[:, 6] += math.pi
+    d_box = (corners - box_utils.boxes_to_corners_3d(gt_bbox3d)).norm(dim=2)
+    d_twin = (corners - box_utils.boxes_to_corners_3d(twin)).norm(dim=2)
+    return _huber(torch.minimum(d_box, d_twin), 1.0).mean(dim=1)
