@@ -108,7 +108,63 @@ __global__ __launch_bounds__(256) void sa_xyz_grad_reduce_kernel(const float* __
     }
 }
 
+// ---- forward: the first layer of a wide SA scale WITHOUT a per-token contraction ------------------------------------------
+// z1[token] = W1 [xyz[idx] - centre | f[idx]] = (W_f f)[idx] + W_xyz (xyz[idx] - centre): a linear layer commutes with the
+// gather.  The feature part is computed once per POINT (P = F W_f^T: b*n rows instead of b*m*nsample -- 4096 instead of
+// 229 376 at ONCE layer 5: 0.5 GFLOP instead of 30) and gathered as rows here; the coordinate part is three FMAs per
+// output on the centred coordinates themselves (no cancellation between large absolute coordinates).
+// thread = 4 consecutive channels of one token; P rows (c1 floats) are L2-resident (4 MB), z1 leaves as 16-byte stores.
+__global__ __launch_bounds__(256) void sa_point_gather_kernel(const float* __restrict__ prow, const float* __restrict__ xyz,
+                                                              const float* __restrict__ new_xyz, const int32_t* __restrict__ idx,
+                                                              const float* __restrict__ w, int ldw, float* __restrict__ z, int n, int m,
+                                                              int ns, int c1, int64_t tokens) {
+    const int cq = c1 >> 2;                                         // channel quads per token
+    // cq divides 256 (c1 in {128, 256, 512, 1024}: the launcher checks): a thread keeps ONE channel quad for the whole walk, so
+    // its 12 coordinate weights are loaded once (per token they would be 12 loads at a 1 KB stride across the wave)
+    const int q = threadIdx.x % cq;
+    float wx[4], wy[4], wz[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float* wr = w + (size_t)(4 * q + k) * ldw;             // W1 row of this channel: columns 0..2 are the coordinates'
+        wx[k] = wr[0]; wy[k] = wr[1]; wz[k] = wr[2];
+    }
+    const int tpb = 256 / cq;                                        // tokens per workgroup step
+    for (int64_t tok = (int64_t)blockIdx.x * tpb + threadIdx.x / cq; tok < tokens; tok += (int64_t)gridDim.x * tpb) {
+        const int64_t grp = tok / ns;
+        const int bs = (int)(grp / m);
+        const int id = idx[tok];
+        const float* pt = xyz + ((size_t)bs * n + id) * 3;
+        const float* ct = new_xyz + grp * 3;
+        const float dx = pt[0] - ct[0], dy = pt[1] - ct[1], dz = pt[2] - ct[2];      // pointnet2_utils.py:692
+        const float4 p4 = *reinterpret_cast<const float4*>(prow + ((size_t)bs * n + id) * c1 + 4 * q);
+        const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(wz[k], dz, __builtin_fmaf(wy[k], dy, __builtin_fmaf(wx[k], dx, pv[k])));
+        *reinterpret_cast<float4*>(z + tok * c1 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 }  // namespace pda
+
+PDA_API int pda_sa_point_gather(const float* point_rows, const float* xyz, const float* new_xyz, const int32_t* idx, const float* w, int ldw,
+                                float* z, int b, int n, int m, int ns, int c1, pda_stream_t stream) {
+    using namespace pda;
+    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && ns >= 1 && c1 >= 4 && (c1 & 3) == 0 && ldw >= 3, "pda_sa_point_gather: bad size");
+    const int64_t tokens = (int64_t)b * m * ns;
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(point_rows && xyz && new_xyz && idx && w && z && (((uintptr_t)point_rows | (uintptr_t)z) & 15) == 0,
+                "pda_sa_point_gather: null or misaligned pointer");
+    if (256 % (c1 >> 2) != 0) {
+        set_error("pda_sa_point_gather: c1 = %d (c1 / 4 must divide 256)", c1);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    const int64_t total = tokens * (c1 >> 2);
+    const int blocks = (int)(divup64(total, 256) < 8192 ? divup64(total, 256) : 8192);
+    hipLaunchKernelGGL(sa_point_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, point_rows, xyz, new_xyz, idx, w, ldw, z, n, m,
+                       ns, c1, tokens);
+    return check_launch("pda_sa_point_gather");
+}
 
 PDA_API int64_t pda_sa_xyz_grad_scratch_bytes(int c1) { return c1 > 0 ? (int64_t)pda::XG_BLOCKS * c1 * 3 * sizeof(float) : 0; }
 

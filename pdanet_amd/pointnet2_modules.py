@@ -421,8 +421,11 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                     w1 = conv1.weight.flatten(1)
                     if (torch.is_grad_enabled() and isinstance(conv1, nn.Conv2d) and conv1.bias is None
                             and pointnet2_utils.SaGatherLinear.supported(xyz, feats_pm, w1)):
-                        # grouping fused into the first contraction: the (B, M, ns, 3 + C) tensor is never built
-                        g = pointnet2_utils.SaGatherLinear.apply(xyz, new_xyz, feats_pm, idxs[i], w1)
+                        # the first contraction never sees a grouped (B, M, ns, 3 + C) tensor: per-point projection + row gather
+                        # (SaPointLinear), or the grouping fused into the contraction (SaGatherLinear)
+                        first = (pointnet2_utils.SaPointLinear if pointnet2_utils.SaPointLinear.supported(xyz, feats_pm, w1)
+                                 else pointnet2_utils.SaGatherLinear)
+                        g = first.apply(xyz, new_xyz, feats_pm, idxs[i], w1)
                         g = _mlp_lastdim(list(self.mlps[i])[1:], g, pool=True, mfma=True)
                         new_features_list.append(g.transpose(1, 2))
                         continue

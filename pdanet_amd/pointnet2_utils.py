@@ -1042,6 +1042,62 @@ class SaGatherLinear(Function):
         return None, g_new, g_feats, None, gw
 
 
+# SA_POINT_LINEAR: the first layer of a wide SA scale as a per-POINT projection + a gather (a linear layer commutes with the
+# gather): z1[token] = (F W_f^T)[idx] + W_xyz (xyz[idx] - centre).  Forward: one (B N, C) x (C, c1) product instead of a
+# (B M ns, 3 + C) one -- 4096 rows instead of 229 376 at ONCE layer 5 -- and a row gather; backward: the token gradients are
+# scatter-added onto the points FIRST (the scatter the grouping gradient needs anyway), then weight and feature gradients
+# are (B N)-row products.  The per-token contraction, its weight gradient and its input gradient (3 x 30 GFLOP per step) are gone.
+SA_POINT_LINEAR = os.environ.get("PDA_SA_POINT_LINEAR", "1") != "0"
+
+
+class SaPointLinear(Function):
+    """SaGatherLinear's contract -- z1 (B, M, ns, C1) = [xyz[idx] - new_xyz | feats[idx]] W1^T -- computed per point."""
+
+    @staticmethod
+    def supported(xyz, feats_pm, weight):
+        return (SA_POINT_LINEAR and SPLIT_GEMM and SaGatherLinear.supported(xyz, feats_pm, weight) and weight.shape[0] in (128, 256, 512, 1024)
+                and feats_pm.shape[0] * feats_pm.shape[1] >= SPLIT_GEMM_MIN_TOKENS)
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, weight):
+        B, N, _ = xyz.shape
+        M, ns = idx.shape[1], idx.shape[2]
+        C, n_out = feats_pm.shape[-1], weight.shape[0]
+        xyz, new_xyz, feats_pm, idx = xyz.contiguous(), new_xyz.contiguous(), feats_pm.contiguous(), idx.contiguous()
+        w = weight.detach().contiguous()
+        w_f = w[:, 3:].contiguous()
+        rows = _gemm_nt(feats_pm.view(B * N, C), w_f)                   # (B N, c1): the feature part, once per point
+        z = torch.empty((B, M, ns, n_out), dtype=torch.float32, device=xyz.device)
+        pointnet2.sa_point_gather(rows, xyz, new_xyz, idx, w, z, B, N, M, ns, n_out)
+        ctx.save_for_backward(xyz, new_xyz, feats_pm, idx, weight)
+        return z
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xyz, new_xyz, feats_pm, idx, weight = ctx.saved_tensors
+        B, M, ns = idx.shape
+        n_out, C, N = weight.shape[0], feats_pm.shape[-1], xyz.shape[1]
+        g2 = grad_out.contiguous().view(-1, n_out)
+        g_new = g_feats = gw = None
+        with torch.no_grad():
+            w = weight.contiguous()
+            if ctx.needs_input_grad[4] or ctx.needs_input_grad[1]:
+                gw = torch.empty_like(weight)
+                g_new = torch.empty_like(new_xyz) if ctx.needs_input_grad[1] else None
+                pointnet2.sa_xyz_grad(g2, xyz, new_xyz, idx, w, gw, g_new, B, N, M, ns, n_out)     # coordinate columns, centres
+            if ctx.needs_input_grad[4] or ctx.needs_input_grad[2]:
+                g_pts = torch.zeros((B, N, n_out), dtype=torch.float32, device=g2.device)
+                pointnet2.group_rows_grad(B, N, n_out, M * ns, g2, idx, g_pts)                    # token gradients onto their points
+                g_pts = g_pts.view(B * N, n_out)
+                if ctx.needs_input_grad[4]:
+                    gw[:, 3:] = _wgrad(feats_pm.view(B * N, C), g_pts, torch.empty((n_out, C), dtype=weight.dtype, device=weight.device), False)[0]
+                if ctx.needs_input_grad[2]:
+                    g_feats = _gemm_nn(g_pts, w[:, 3:].contiguous()).view(B, N, C)
+            if not ctx.needs_input_grad[4]:
+                gw = None
+        return None, g_new, g_feats, None, gw
+
+
 # ---- the narrow vanilla SA scale (layer 0) in training form as recompute passes (csrc/sa_train_small.hip) ------------
 # SA_SMALL_TRAIN: group -> [conv1x1 -> BN(batch statistics) -> ReLU] x 3 -> max of a scale whose widths are <= 64 runs as
 # four forward and four backward passes over the neighbour lists; no (B, M, ns, C) tensor exists in the forward pass.

@@ -122,3 +122,28 @@ def test_sa_xyz_grad_kernel_against_fp64(b, n, m, ns, c1):
     assert (dw[:, :3].double() - want_dw).abs().max().item() <= 2e-5 * want_dw.abs().max().item()
     assert (dw[:, 3:] == 7.0).all()                       # the feature columns are not this kernel's
     assert (gnew.double() - want_new).abs().max().item() <= 2e-5 * want_new.abs().max().item()
+
+
+def test_sa_point_linear_equals_gather_linear():
+    """SaPointLinear (per-point projection + row gather; backward: scatter first, then (B N)-row products) against
+    SaGatherLinear (the per-token contraction): the same z1 and the same gradients for weight, features and centres."""
+    from pdanet_amd import pointnet2_utils as pu, synth
+    B, N, M, ns, C, c1 = 2, 2048, 1024, 32, 256, 256
+    xyz = torch.from_numpy(synth.batch_xyz(B, N, config_id=6)).cuda()
+    g = torch.Generator().manual_seed(4)
+    ctr0 = (xyz[:, :M] + 0.2 * torch.randn(B, M, 3, generator=g).cuda()).contiguous()
+    idx = pu.ball_query(8.4, ns, xyz, ctr0)
+    feats0 = torch.randn(B, N, C, generator=g).cuda()
+    w0 = (torch.randn(c1, 3 + C, generator=g) * 0.05).cuda()
+    gz = torch.randn(B, M, ns, c1, generator=g).cuda()
+    res = []
+    for fn in (pu.SaPointLinear, pu.SaGatherLinear):
+        ctr, feats, w = ctr0.clone().requires_grad_(True), feats0.clone().requires_grad_(True), w0.clone().requires_grad_(True)
+        assert fn.supported(xyz, feats, w)
+        z = fn.apply(xyz, ctr, feats, idx, w)
+        z.backward(gz)
+        res.append((z.detach(), ctr.grad, feats.grad, w.grad))
+    (za, ca, fa, wa), (zb, cb, fb, wb) = res
+    assert (za - zb).abs().max().item() <= 2e-5 * zb.abs().max().item()
+    for a, b, name in ((ca, cb, "centres"), (fa, fb, "features"), (wa, wb, "weight")):
+        assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item(), name
