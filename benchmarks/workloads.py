@@ -505,8 +505,26 @@ class BackboneInferWorkload(BackboneWorkload):
         return bd['centers_features']
 
     def rooflines(self):
-        return {"roofline": self.roofline_sa_mlp(), "roofline_fps": self.roofline_fps(),
-                "roofline_ball_query": self.roofline_ball_query()}
+        return {"roofline": self.roofline_sa_wide_infer() or self.roofline_sa_mlp(), "roofline_fused_sa_kernel": self.roofline_sa_mlp(),
+                "roofline_fps": self.roofline_fps(), "roofline_ball_query": self.roofline_ball_query()}
+
+    def roofline_sa_wide_infer(self):
+        """The wide SA scales (layer 5) in inference: per-point first layer + split-bf16 GEMMs for layers 2 and 3
+        (pointnet2_utils.sa_wide_scale_infer).  achieved = 6 x the flops of layers 2 and 3 / the time of the whole scale
+        (gather of the first layer and the max-pool included), against the dense bf16 peak."""
+        ev = [e for e in self.sa_mfma_events if e[3] == "bf16x6_infer"]
+        if not ev:
+            return None
+        t = sum(e[0].elapsed_time(e[1]) for e in ev) * 1e-3
+        fl = sum(e[2] for e in ev)
+        steps = max(1, len(self.fps_events))
+        work = SPLIT_PRODUCTS * fl / t / 1e12
+        return {"kernel": "sa_wide_scale_infer: sa_point_gather_kernel + gemm_split_wide_kernel / lin_split_kernel (+ max-pool), %d scales per step" % (len(ev) // steps),
+                "bound": "mfma", "achieved": work, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": work / BF16_MFMA_PEAK_TF,
+                "achieved_f32_equiv": fl / t / 1e12, "peak_f32_input_mfma": F32_MFMA_PEAK_TF, "traffic": None,
+                "ms_per_step": t / steps * 1e3, "gflop_per_step": fl / steps / 1e9,
+                "note": "flops of layers 2 and 3 only (the first layer is a per-point projection of 0.5 GFLOP + a row gather); time of "
+                        "the whole scale.  PDA_SA_WIDE_INFER_SPLIT=0 restores the fused f32-MFMA kernel (roofline_fused_sa_kernel)"}
 
     def roofline_sa_mlp(self):
         """Dominant fused kernel = the launch shape with the largest mean duration."""

@@ -316,9 +316,11 @@ int pda_sa_small_train_bwd(const float *xyz, const float *new_xyz, const float *
 int64_t pda_sa_xyz_grad_scratch_bytes(int c1);
 /* Forward of the same layer without a per-token contraction (a linear layer commutes with the gather):
  * z (b*m*nsample, c1) = point_rows[idx] + W1[:, 0:3] (xyz[idx] - new_xyz[centre]), with point_rows (b*n, c1) = features W1[:, 3:]^T
- * computed once per point by the caller (pda_gemm_split).  c1 a multiple of 4. */
+ * computed once per point by the caller (pda_gemm_split); optional bias (c1) and ReLU (inference: BatchNorm folded into W1).
+ * c1 in {128, 256, 512, 1024}. */
 int pda_sa_point_gather(const float *point_rows, const float *xyz, const float *new_xyz, const int32_t *idx, const float *w,
-                        int ldw, float *z, int b, int n, int m, int nsample, int c1, pda_stream_t stream);
+                        int ldw, const float *bias, int relu, float *z, int b, int n, int m, int nsample, int c1,
+                        pda_stream_t stream);
 int pda_sa_xyz_grad(const float *grad_z1, const float *xyz, const float *new_xyz, const int32_t *idx, const float *w, int ldw,
                     float *dw, int lddw, float *grad_new_xyz, void *scratch, int b, int n, int m, int nsample, int c1,
                     pda_stream_t stream);

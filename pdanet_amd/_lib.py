@@ -120,7 +120,7 @@ SIGNATURES = {
     "pda_sa_small_train_fwd": [_vp] * 7 + [ctypes.POINTER(_vp)] * 4 + [ctypes.POINTER(_f)] * 2 + [_vp] * 4 + [_i] * 8 + [_vp],
     "pda_sa_small_train_bwd": [_vp] * 13 + [ctypes.POINTER(_vp)] * 2 + [_i] * 8 + [_vp],
     "pda_sa_xyz_grad_scratch_bytes": [_i],
-    "pda_sa_point_gather": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "pda_sa_point_gather": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_sa_xyz_grad": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pda_adam_onecycle_step": [_vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp],
     # include/pda_pointnet2_stack.h

@@ -116,8 +116,9 @@ __global__ __launch_bounds__(256) void sa_xyz_grad_reduce_kernel(const float* __
 // thread = 4 consecutive channels of one token; P rows (c1 floats) are L2-resident (4 MB), z1 leaves as 16-byte stores.
 __global__ __launch_bounds__(256) void sa_point_gather_kernel(const float* __restrict__ prow, const float* __restrict__ xyz,
                                                               const float* __restrict__ new_xyz, const int32_t* __restrict__ idx,
-                                                              const float* __restrict__ w, int ldw, float* __restrict__ z, int n, int m,
-                                                              int ns, int c1, int64_t tokens) {
+                                                              const float* __restrict__ w, int ldw, const float* __restrict__ bias,
+                                                              int relu, float* __restrict__ z, int n, int m, int ns, int c1,
+                                                              int64_t tokens) {
     const int cq = c1 >> 2;                                         // channel quads per token
     // cq divides 256 (c1 in {128, 256, 512, 1024}: the launcher checks): a thread keeps ONE channel quad for the whole walk, so
     // its 12 coordinate weights are loaded once (per token they would be 12 loads at a 1 KB stride across the wave)
@@ -128,6 +129,8 @@ __global__ __launch_bounds__(256) void sa_point_gather_kernel(const float* __res
         const float* wr = w + (size_t)(4 * q + k) * ldw;             // W1 row of this channel: columns 0..2 are the coordinates'
         wx[k] = wr[0]; wy[k] = wr[1]; wz[k] = wr[2];
     }
+    float bq[4] = {0.f, 0.f, 0.f, 0.f};                             // inference: the folded BatchNorm shift, then ReLU
+    if (bias) { const float4 b4 = *reinterpret_cast<const float4*>(bias + 4 * q); bq[0] = b4.x; bq[1] = b4.y; bq[2] = b4.z; bq[3] = b4.w; }
     const int tpb = 256 / cq;                                        // tokens per workgroup step
     for (int64_t tok = (int64_t)blockIdx.x * tpb + threadIdx.x / cq; tok < tokens; tok += (int64_t)gridDim.x * tpb) {
         const int64_t grp = tok / ns;
@@ -140,7 +143,10 @@ __global__ __launch_bounds__(256) void sa_point_gather_kernel(const float* __res
         const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
         float o[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = __builtin_fmaf(wz[k], dz, __builtin_fmaf(wy[k], dy, __builtin_fmaf(wx[k], dx, pv[k])));
+        for (int k = 0; k < 4; ++k) {
+            o[k] = __builtin_fmaf(wz[k], dz, __builtin_fmaf(wy[k], dy, __builtin_fmaf(wx[k], dx, pv[k]))) + bq[k];
+            o[k] = relu ? fmaxf(o[k], 0.f) : o[k];
+        }
         *reinterpret_cast<float4*>(z + tok * c1 + 4 * q) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
@@ -148,12 +154,12 @@ __global__ __launch_bounds__(256) void sa_point_gather_kernel(const float* __res
 }  // namespace pda
 
 PDA_API int pda_sa_point_gather(const float* point_rows, const float* xyz, const float* new_xyz, const int32_t* idx, const float* w, int ldw,
-                                float* z, int b, int n, int m, int ns, int c1, pda_stream_t stream) {
+                                const float* bias, int relu, float* z, int b, int n, int m, int ns, int c1, pda_stream_t stream) {
     using namespace pda;
     PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && ns >= 1 && c1 >= 4 && (c1 & 3) == 0 && ldw >= 3, "pda_sa_point_gather: bad size");
     const int64_t tokens = (int64_t)b * m * ns;
     if (tokens == 0) return PDA_OK;
-    PDA_REQUIRE(point_rows && xyz && new_xyz && idx && w && z && (((uintptr_t)point_rows | (uintptr_t)z) & 15) == 0,
+    PDA_REQUIRE(point_rows && xyz && new_xyz && idx && w && z && (((uintptr_t)point_rows | (uintptr_t)z | (uintptr_t)bias) & 15) == 0,
                 "pda_sa_point_gather: null or misaligned pointer");
     if (256 % (c1 >> 2) != 0) {
         set_error("pda_sa_point_gather: c1 = %d (c1 / 4 must divide 256)", c1);
@@ -161,8 +167,8 @@ PDA_API int pda_sa_point_gather(const float* point_rows, const float* xyz, const
     }
     const int64_t total = tokens * (c1 >> 2);
     const int blocks = (int)(divup64(total, 256) < 8192 ? divup64(total, 256) : 8192);
-    hipLaunchKernelGGL(sa_point_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, point_rows, xyz, new_xyz, idx, w, ldw, z, n, m,
-                       ns, c1, tokens);
+    hipLaunchKernelGGL(sa_point_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, point_rows, xyz, new_xyz, idx, w, ldw, bias, relu, z,
+                       n, m, ns, c1, tokens);
     return check_launch("pda_sa_point_gather");
 }
 

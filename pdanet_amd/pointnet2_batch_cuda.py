@@ -730,12 +730,13 @@ def sa_xyz_grad(grad_z1, xyz, new_xyz, idx, w, dw, grad_new_xyz, b, n, m, ns, c1
     return 1
 
 
-def sa_point_gather(point_rows, xyz, new_xyz, idx, w, z, b, n, m, ns, c1):
+def sa_point_gather(point_rows, xyz, new_xyz, idx, w, z, b, n, m, ns, c1, bias=None, relu=False):
     """MI355X extension: z (b*m*ns, c1) = point_rows[idx] + w[:, 0:3] (xyz[idx] - new_xyz[centre]) (csrc/sa_xyz_grad.hip): the
     first layer of a wide SA scale from its per-point projection point_rows (b*n, c1) = features w[:, 3:]^T."""
     _numel_ok(point_rows, b * n * c1, "point_rows"); _numel_ok(z, b * m * ns * c1, "z"); _numel_ok(idx, b * m * ns, "idx")
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz")
     assert w.shape[0] == c1 and w.shape[1] >= 3
     _call("pda_sa_point_gather", xyz, _chk(point_rows, "point_rows", F32), _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32),
-          _chk(idx, "idx", I32), _chk(w, "w", F32), int(w.shape[1]), _chk(z, "z", F32), b, n, m, ns, c1)
+          _chk(idx, "idx", I32), _chk(w, "w", F32), int(w.shape[1]), None if bias is None else _chk(bias, "bias", F32),
+          1 if relu else 0, _chk(z, "z", F32), b, n, m, ns, c1)
     return 1

@@ -406,6 +406,15 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
             for i in range(len(self.groupers)):
                 if self.fused is not None and plain_ball and self.pool_method == 'max_pool' \
                         and not self.training and not torch.is_grad_enabled():
+                    seq = list(self.mlps[i])
+                    if (use_cl and feats_pm is not None and feats_pm.shape[-1] >= 128 and len(seq) == 9
+                            and all(_can_fold(seq[3 * k], seq[3 * k + 1]) for k in range(3))):
+                        # wide scale (layer 5): per-point first layer + split-bf16 GEMMs beat the fused f32-MFMA kernel
+                        g = pointnet2_utils.sa_wide_scale_infer(xyz, new_xyz, feats_pm, idxs[i],
+                                                                [_folded_conv_bn(seq[3 * k], seq[3 * k + 1]) for k in range(3)])
+                        if g is not None:
+                            new_features_list.append(g.transpose(1, 2))
+                            continue
                     pooled = self.fused(i, self, xyz, new_xyz, features, idxs[i])  # (B, mlp[-1], npoint) | None
                     if pooled is not None:
                         new_features_list.append(pooled)

@@ -1098,6 +1098,39 @@ class SaPointLinear(Function):
         return None, g_new, g_feats, None, gw
 
 
+SA_WIDE_INFER_SPLIT = os.environ.get("PDA_SA_WIDE_INFER_SPLIT", "1") != "0"
+
+
+def sa_wide_scale_infer(xyz, new_xyz, feats_pm, idx, folded):
+    """One WIDE vanilla SA scale in inference (BatchNorm folded into the convolutions: `folded` = [(W, b)] x 3): the first
+    layer as per-point projection + row gather with bias and ReLU (sa_point_gather), layers 2 and 3 on the split-bf16 GEMMs
+    with bias + ReLU in their epilogue, then the max over nsample.  172 GFLOP of ONCE layer 5 become 142 on the bf16 matrix
+    cores (f32-grade) instead of 172 on the f32-input MFMA of the fused kernel.  Returns (B, M, c3) or None (shape not covered)."""
+    (w1, b1), (w2, b2), (w3, b3) = folded
+    B, N, _ = xyz.shape
+    M, ns = idx.shape[1], idx.shape[2]
+    C = feats_pm.shape[-1]
+    T = B * M * ns
+    c1, c2, c3 = w1.shape[0], w2.shape[0], w3.shape[0]
+    if not (SA_WIDE_INFER_SPLIT and SPLIT_GEMM and not DENSE_BF16 and w1.shape[1] == 3 + C and C % 32 == 0 and c1 in (128, 256, 512, 1024)
+            and c1 % 32 == 0 and c2 % 128 == 0 and c3 % 128 == 0 and B * N >= SPLIT_GEMM_MIN_TOKENS and T >= SPLIT_GEMM_MIN_TOKENS):
+        return None
+    out = []
+
+    def run():
+        rows = _gemm_nt(feats_pm.reshape(B * N, C), w1[:, 3:].contiguous())
+        y1 = torch.empty((T, c1), dtype=torch.float32, device=xyz.device)
+        pointnet2.sa_point_gather(rows, xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), w1, y1, B, N, M, ns, c1, bias=b1, relu=True)
+        y2 = _gemm_nt(y1, w2, b2, relu=True)
+        del y1
+        y3 = _gemm_nt(y2, w3, b3, relu=True)
+        del y2
+        out.append(y3.view(B, M, ns, c3).amax(dim=2))
+    # bench: (layers 2 + 3 flops, the part that runs on the bf16 pipe), timed over the whole scale incl. gather and max-pool
+    _sa_timed(2.0 * T * (c1 * c2 + c2 * c3), run, "bf16x6_infer")
+    return out[0]
+
+
 # ---- the narrow vanilla SA scale (layer 0) in training form as recompute passes (csrc/sa_train_small.hip) ------------
 # SA_SMALL_TRAIN: group -> [conv1x1 -> BN(batch statistics) -> ReLU] x 3 -> max of a scale whose widths are <= 64 runs as
 # four forward and four backward passes over the neighbour lists; no (B, M, ns, C) tensor exists in the forward pass.

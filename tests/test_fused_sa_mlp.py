@@ -33,7 +33,19 @@ def make_layer(c_in, mlps, radii, nsamples, npoint):
     (1, [[16, 16, 32]], [2.0], [8], 1000, 33),                                     # ns 8, odd sizes
     (256, [[256, 256, 512]], [20.0], [128], 512, 16),                              # ns 128: 4 waves per group
 ])
-def test_fused_matches_unfused(c_in, mlps, radii, nsamples, n, m):
+@pytest.mark.parametrize("wide_split", [False, True])
+def test_fused_matches_unfused(c_in, mlps, radii, nsamples, n, m, wide_split):
+    """wide_split = False: every scale on the fused f32-MFMA kernel (csrc/sa_mlp.hip); True (the default): the wide scales
+    take the per-point first layer + split-bf16 GEMMs (pointnet2_utils.sa_wide_scale_infer) where the sizes allow it."""
+    from pdanet_amd import synth, fused_ops, pointnet2_utils as pu
+    keep, pu.SA_WIDE_INFER_SPLIT = pu.SA_WIDE_INFER_SPLIT, wide_split
+    try:
+        _fused_matches_unfused(c_in, mlps, radii, nsamples, n, m)
+    finally:
+        pu.SA_WIDE_INFER_SPLIT = keep
+
+
+def _fused_matches_unfused(c_in, mlps, radii, nsamples, n, m):
     from pdanet_amd import synth, fused_ops
     xyz = torch.from_numpy(synth.batch_xyz(2, n, config_id=n + m)).cuda()
     feats = torch.randn(2, c_in, n, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
@@ -42,7 +54,7 @@ def test_fused_matches_unfused(c_in, mlps, radii, nsamples, n, m):
         ref_xyz, ref, _, ref_idx = layer(xyz, feats, None)
         assert fused_ops.enable_fused(layer) == 1
         new_xyz, out, _, idx = layer(xyz, feats, None)
-    assert not layer.fused.unsupported, "fused kernel was not used: %s" % layer.fused.unsupported
+    assert not layer.fused.unsupported, "fused kernel refused a chain: %s" % layer.fused.unsupported
     assert torch.equal(ref_idx, idx) and torch.equal(ref_xyz, new_xyz)
     assert out.shape == ref.shape
     scale = float(ref.abs().max())
