@@ -20,82 +20,86 @@
 
 namespace pda {
 
-// ellipsoid_query_gpu.cu:58-298 for n = 3
-__device__ void eq_jacobi3(float (&a)[9], int it_max, float (&v)[9], float (&d)[3]) {
-    constexpr int n = 3;
-    float bw[3], zw[3];
-    for (int j = 0, k = 0; j < n; ++j)
-        for (int i = 0; i < n; ++i) v[k++] = i == j ? 1.0f : 0.0f;
-    for (int i = 0; i < n; ++i) { d[i] = a[i + i * n]; bw[i] = d[i]; zw[i] = 0.0f; }
-    int it_num = 0;
-    while (it_num < it_max) {
-        ++it_num;
-        float thresh = 0.0f;
-        for (int j = 0; j < n; ++j)
-            for (int i = 0; i < j; ++i) thresh = thresh + a[i + j * n] * a[i + j * n];
-        thresh = __fsqrt_rn(thresh) / (float)(4 * n);
-        if (thresh == 0.0f) break;
-        for (int p = 0; p < n; ++p)
-            for (int q = p + 1; q < n; ++q) {
-                const float gapq = (float)(10.0 * (double)fabsf(a[p + q * n]));
-                const float termp = gapq + fabsf(d[p]);
-                const float termq = gapq + fabsf(d[q]);
-                if (4 < it_num && termp == fabsf(d[p]) && termq == fabsf(d[q])) {
-                    a[p + q * n] = 0.0f;
-                } else if (thresh <= fabsf(a[p + q * n])) {
-                    float h = d[q] - d[p];
-                    const float term = fabsf(h) + gapq;
-                    float t;
-                    if (term == fabsf(h)) {
-                        t = a[p + q * n] / h;
-                    } else {
-                        const float theta = (float)(0.5 * (double)h / (double)a[p + q * n]);
-                        t = (float)(1.0 / ((double)fabsf(theta) + __dsqrt_rn(1.0 + (double)(theta * theta))));
-                        if (theta < 0.0f) t = -t;
-                    }
-                    const float c = (float)(1.0 / __dsqrt_rn(1.0 + (double)(t * t)));
-                    const float s = t * c;
-                    const float tau = (float)((double)s / (1.0 + (double)c));
-                    h = t * a[p + q * n];
-                    zw[p] = zw[p] - h; zw[q] = zw[q] + h;
-                    d[p] = d[p] - h; d[q] = d[q] + h;
-                    a[p + q * n] = 0.0f;
-                    for (int j = 0; j < p; ++j) {
-                        const float g = a[j + p * n]; h = a[j + q * n];
-                        a[j + p * n] = g - s * (h + g * tau);
-                        a[j + q * n] = h + s * (g - h * tau);
-                    }
-                    for (int j = p + 1; j < q; ++j) {
-                        const float g = a[p + j * n]; h = a[j + q * n];
-                        a[p + j * n] = g - s * (h + g * tau);
-                        a[j + q * n] = h + s * (g - h * tau);
-                    }
-                    for (int j = q + 1; j < n; ++j) {
-                        const float g = a[p + j * n]; h = a[q + j * n];
-                        a[p + j * n] = g - s * (h + g * tau);
-                        a[q + j * n] = h + s * (g - h * tau);
-                    }
-                    for (int j = 0; j < n; ++j) {
-                        const float g = v[j + p * n]; h = v[j + q * n];
-                        v[j + p * n] = g - s * (h + g * tau);
-                        v[j + q * n] = h + s * (g - h * tau);
-                    }
-                }
-            }
-        for (int i = 0; i < n; ++i) { bw[i] = bw[i] + zw[i]; d[i] = bw[i]; zw[i] = 0.0f; }
+// Eigen-decomposition of a symmetric 3x3 matrix by cyclic Jacobi rotations: the sweep order (0,1), (0,2), (1,2), the
+// threshold, the small-element rule after four sweeps, the rotation formulas and the final ascending sort are those of
+// the routine the reference calls (ellipsoid_query_gpu.cu:58-298, n = 3), so that the axes -- and with them the second
+// query -- come out the same; written for the three off-diagonal elements as scalars instead of an n x n array.
+// On return: evec[3 k + i] = component i of the eigenvector of the k-th smallest eigenvalue.
+struct Sym3Jacobi {
+    float diag[3];          // running diagonal
+    float off[3];           // upper triangle: off[0] = (0,1), off[1] = (0,2), off[2] = (1,2)
+    float evec[9];          // column-major eigenvector estimate
+    float base[3], corr[3]; // diagonal at the start of the sweep and the corrections gathered during it
+
+    // the plane rotation applied to a pair (g, h): g' = g - s (h + g tau), h' = h + s (g - h tau)
+    static __device__ __forceinline__ void spin(float& g, float& h, float s, float tau) {
+        const float g0 = g, h0 = h;
+        g = g0 - s * (h0 + g0 * tau);
+        h = h0 + s * (g0 - h0 * tau);
     }
-    for (int j = 0; j < n; ++j)
-        for (int i = 0; i < j; ++i) a[i + j * n] = a[j + i * n];
-    for (int k = 0; k < n - 1; ++k) {
-        int m = k;
-        for (int l = k + 1; l < n; ++l)
-            if (d[l] < d[m]) m = l;
-        if (m != k) {
-            const float t = d[m]; d[m] = d[k]; d[k] = t;
-            for (int i = 0; i < n; ++i) { const float w = v[i + m * n]; v[i + m * n] = v[i + k * n]; v[i + k * n] = w; }
+
+    // one (p, q) step of a sweep; `e` is the off-diagonal element (p, q), (x, y) the two other off-diagonal elements in
+    // the order the rotation pairs them
+    __device__ __forceinline__ void step(int p, int q, float& e, float& x, float& y, bool late, float floor_) {
+        const float mag = fabsf(e);
+        const float guard = (float)(10.0 * (double)mag);
+        if (late && guard + fabsf(diag[p]) == fabsf(diag[p]) && guard + fabsf(diag[q]) == fabsf(diag[q])) {
+            e = 0.0f;                                   // too small to change either eigenvalue any more
+            return;
+        }
+        if (!(floor_ <= mag)) return;
+        const float gap = diag[q] - diag[p];
+        float t;
+        if (fabsf(gap) + guard == fabsf(gap)) {
+            t = e / gap;
+        } else {
+            const float theta = (float)(0.5 * (double)gap / (double)e);
+            t = (float)(1.0 / ((double)fabsf(theta) + __dsqrt_rn(1.0 + (double)(theta * theta))));
+            t = theta < 0.0f ? -t : t;
+        }
+        const float c = (float)(1.0 / __dsqrt_rn(1.0 + (double)(t * t)));
+        const float s = t * c;
+        const float tau = (float)((double)s / (1.0 + (double)c));
+        const float shift = t * e;
+        corr[p] = corr[p] - shift; corr[q] = corr[q] + shift;
+        diag[p] = diag[p] - shift; diag[q] = diag[q] + shift;
+        e = 0.0f;
+        spin(x, y, s, tau);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) spin(evec[3 * p + i], evec[3 * q + i], s, tau);
+    }
+
+    __device__ void run(const float (&m)[9], int max_sweeps) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) evec[k] = (k % 4 == 0) ? 1.0f : 0.0f;
+        diag[0] = m[0]; diag[1] = m[4]; diag[2] = m[8];
+        off[0] = m[3]; off[1] = m[6]; off[2] = m[7];            // a[i + 3 j] with i < j
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { base[i] = diag[i]; corr[i] = 0.0f; }
+        for (int sweep = 1; sweep <= max_sweeps; ++sweep) {
+            float ss = 0.0f;
+            ss = ss + off[0] * off[0]; ss = ss + off[1] * off[1]; ss = ss + off[2] * off[2];
+            const float floor_ = __fsqrt_rn(ss) / 12.0f;
+            if (floor_ == 0.0f) break;
+            const bool late = sweep > 4;
+            step(0, 1, off[0], off[1], off[2], late, floor_);   // (0,1) pairs (0,2) with (1,2)
+            step(0, 2, off[1], off[0], off[2], late, floor_);   // (0,2) pairs (0,1) with (1,2)
+            step(1, 2, off[2], off[0], off[1], late, floor_);   // (1,2) pairs (0,1) with (0,2)
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { base[i] = base[i] + corr[i]; diag[i] = base[i]; corr[i] = 0.0f; }
+        }
+        // ascending eigenvalues (selection sort, as the reference orders them), eigenvector columns follow
+        for (int k = 0; k < 2; ++k) {
+            int lo = k;
+            for (int l = k + 1; l < 3; ++l) lo = diag[l] < diag[lo] ? l : lo;
+            if (lo != k) {
+                const float d0 = diag[lo]; diag[lo] = diag[k]; diag[k] = d0;
+#pragma unroll
+                for (int i = 0; i < 3; ++i) { const float w = evec[3 * lo + i]; evec[3 * lo + i] = evec[3 * k + i]; evec[3 * k + i] = w; }
+            }
         }
     }
-}
+};
 
 // idx (b, m, nsample) holds the rows of the ball query of radius e3; one thread per centre re-orients and extends its row
 __global__ __launch_bounds__(64) void ellipsoid_refine_kernel(const float* __restrict__ new_xyz_all, const float* __restrict__ xyz_all,
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(64) void ellipsoid_refine_kernel(const float* __res
     float v[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
     float sg = -1.0f;
     if (act) {
-        float cva[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, dd[3];
+        float cva[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
         bool flag = false;
         float means[3] = {0.0f, 0.0f, 0.0f};
         for (int k = 0; k < pts; ++k) {
@@ -146,7 +150,10 @@ __global__ __launch_bounds__(64) void ellipsoid_refine_kernel(const float* __res
 #pragma unroll
             for (int e = 0; e < 9; ++e) cva[e] = acc[e] / (float)(pts - 1);
         }
-        eq_jacobi3(cva, 1000, v, dd);
+        Sym3Jacobi jac;
+        jac.run(cva, 1000);
+#pragma unroll
+        for (int e = 0; e < 9; ++e) v[e] = jac.evec[e];
         const float deter = v[6] * (v[4] * v[2] - v[1] * v[5]) - v[7] * (v[3] * v[2] - v[0] * v[5]) + v[8] * (v[3] * v[1] - v[0] * v[4]);
         sg = deter == 1.0f ? 1.0f : -1.0f;
     }
