@@ -622,7 +622,8 @@ def _split_planes(w, transposed=False):
         wf, wft = (ent[1] if ent is not None else None), pack(True)
     else:
         wf, wft = pack(False), (ent[2] if ent is not None else None)
-    _PACKED_PLANES[key] = (tag, wf, wft, weakref.ref(param), key - param.data_ptr())
+    # (the entry goes with its parameter: a callback on the weak reference, as for the bf16 copies above)
+    _PACKED_PLANES[key] = (tag, wf, wft, weakref.ref(param, lambda _r, k=key: _PACKED_PLANES.pop(k, None)), key - param.data_ptr())
     return wft if transposed else wf
 
 
