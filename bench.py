@@ -87,6 +87,16 @@ def time_workload(wl, steps, warmup, device, parallel):
     return parallel.max_over_ranks(dt, device)
 
 
+def safe(fn, default, *a):
+    """The timing is the measurement; a failure in a secondary leg (roofline bookkeeping, CPU baseline) must not cost the line.
+    The error text is kept in place of the value."""
+    try:
+        return fn(*a)
+    except Exception as e:  # noqa: BLE001
+        print("bench.py: %s failed: %r" % (getattr(fn, "__name__", fn), e), file=sys.stderr)
+        return dict(default, error=repr(e)) if isinstance(default, dict) else default
+
+
 def metric_name(wl_name, points):
     ds = "KITTI" if wl_name.startswith("kitti") else "ONCE"
     if "fwd_bwd" in wl_name:
@@ -160,7 +170,7 @@ def main():
     if args.warmup < 5 and getattr(wl, "_tail_auto", False):
         wl._tail_auto = False        # the probe (iteration 4) and the capture behind it (iteration 5) must stay out of the timed steps
     dt = time_workload(wl, args.steps, args.warmup, device, parallel)
-    roofs = wl.rooflines()
+    roofs = safe(wl.rooflines, {})
 
     line = {
         "metric": metric_name(wl.name, args.points),
@@ -195,13 +205,13 @@ def main():
 
     single = world == 1 and rank == 0
     if single and not args.no_cpu_baseline:
-        line["cpu_baseline"] = wl.cpu_baseline()
+        line["cpu_baseline"] = safe(wl.cpu_baseline, {"value": None, "unit": "scenes/s", "cores": None, "kind": "port", "sample": "failed"})
         # the operator baseline "at 1 thread and at all cores"
         xyz_np = getattr(wl, "xyz_np", None)
         if xyz_np is None:
             xyz_np = wl.points_np[: args.points, 1:4].reshape(1, args.points, 3).copy()
-        line["cpu_baseline_ops"] = {"threads_1": workloads.sampling_grouping_cpu(xyz_np, 1),
-                                    "threads_all": workloads.sampling_grouping_cpu(xyz_np, None)}
+        line["cpu_baseline_ops"] = {"threads_1": safe(workloads.sampling_grouping_cpu, {}, xyz_np, 1),
+                                    "threads_all": safe(workloads.sampling_grouping_cpu, {}, xyz_np, None)}
 
     if single and not args.no_extra and args.workload == "auto":
         # secondary timings (few steps each): round 1's headline and BASELINE configs[1] / configs[2]
@@ -211,17 +221,21 @@ def main():
         # GEMMs, dense encoder) and the default mode (f32 tensors, every large contraction as a 3-term bf16 split on the bf16
         # matrix cores, unique-token encoder)
         for xname, xbatch in (("backbone", 2), ("backbone_infer", 2), ("kitti_detector_train_bf16", 4), ("kitti_detector_train", 4)):
-            torch.cuda.empty_cache()
-            xw = workloads.create(xname, xbatch, args.points, device, rank, world)
-            xsteps = max(5, min(args.steps, 10))
-            xdt = time_workload(xw, xsteps, 6, device, parallel)     # two warm-up steps left first-use costs (allocator growth, library heuristics) in the timed ones
-            xr = xw.rooflines()
-            extra[xname] = {"workload": xw.name, "step": step_text(xw.name), "scenes_per_gpu": xbatch,
-                            "steps": xsteps, "ms_per_step": xdt / xsteps * 1e3, "scenes_per_s": xbatch * xsteps / xdt,
-                            "dtype": xw.dtype}
-            if xname == "backbone_infer" and xr.get("roofline") is not None:
-                extra[xname]["roofline_mfma_fused_sa"] = xr["roofline"]
-            del xw
+            try:
+                torch.cuda.empty_cache()
+                xw = workloads.create(xname, xbatch, args.points, device, rank, world)
+                xsteps = max(5, min(args.steps, 10))
+                xdt = time_workload(xw, xsteps, 6, device, parallel)     # two warm-up steps left first-use costs (allocator growth, library heuristics) in the timed ones
+                xr = safe(xw.rooflines, {})
+                extra[xname] = {"workload": xw.name, "step": step_text(xw.name), "scenes_per_gpu": xbatch,
+                                "steps": xsteps, "ms_per_step": xdt / xsteps * 1e3, "scenes_per_s": xbatch * xsteps / xdt,
+                                "dtype": xw.dtype}
+                if xname == "backbone_infer" and xr.get("roofline") is not None:
+                    extra[xname]["roofline_mfma_fused_sa"] = xr["roofline"]
+                del xw
+            except Exception as e:  # noqa: BLE001  (a secondary timing must not cost the headline line)
+                print("bench.py: extra workload %s failed: %r" % (xname, e), file=sys.stderr)
+                extra[xname] = {"error": repr(e)}
         line["extra"] = extra
 
     if rank == 0:
