@@ -75,6 +75,7 @@ struct LinSplitParams {
     float* y;               // (T, N) row-major
     int64_t tokens;
     int k, n_out, chunks, relu;
+    int cpb;                    // output chunks per workgroup: blockIdx.y owns chunks [cpb * y, cpb * (y + 1))
     unsigned long long* dbg;    // GS_PROFILE builds: per-workgroup phase clocks
 };
 #ifdef GS_PROFILE
@@ -98,6 +99,8 @@ void lin_split_kernel(const LinSplitParams p) {
     const int64_t tk = tok0 + j < p.tokens ? tok0 + j : p.tokens - 1;
     const uint4* src = p.wf + tid;
     const int ntiles = p.chunks * NG;
+    // few tokens: the output chunks are spread over blockIdx.y as well (a 4096-token product is 32 workgroups otherwise)
+    const int c0 = (int)blockIdx.y * p.cpb, c1 = min(p.chunks, c0 + p.cpb);
     const uint32_t ring_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)ring + w * 1024;
     auto issue = [&](int t, int slot) {          // tile t -> ring slot (the tile behind the last is the last again)
         const uint4* g = src + (size_t)(t < ntiles ? t : ntiles - 1) * TILE;
@@ -120,8 +123,8 @@ void lin_split_kernel(const LinSplitParams p) {
     for (int i = tid; i < p.n_out; i += 256) bias_s[i] = p.bias ? p.bias[i] : 0.f;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the row loads: nothing ordinary in flight beside the DMA below
     GS_MARK(1);
-    issue(0, 0);
-    issue(1, 1);
+    issue(c0 * NG, 0);
+    issue(c0 * NG + 1, 1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NLD) : "memory");
     __builtin_amdgcn_s_barrier();
     GS_MARK(2);
@@ -139,9 +142,9 @@ void lin_split_kernel(const LinSplitParams p) {
         if (whole) row[lane_off] = v;
         else if (t < left) row[lane_off] = v;
     };
-    int ti = 0, slot = 0;                        // slot = ti % 3
+    int ti = c0 * NG, slot = 0;                  // slot = (ti - c0 * NG) % 3
     gs_f32x16 done[4];                           // results of the previous chunk, stored under the next chunk's first tile
-    for (int c = 0; c < p.chunks; ++c) {
+    for (int c = c0; c < c1; ++c) {
         gs_f32x16 acc[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
@@ -196,7 +199,7 @@ void lin_split_kernel(const LinSplitParams p) {
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wm, acc[r], 0, 0, 0);
                     acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Xh, Wh, acc[r], 0, 0, 0);
                     if (q < NLD) glds16(dsrc + 256 * q, ddst + 4096 * q);
-                    if (c > 0) {
+                    if (c > c0) {
                         constexpr int GROUPS = KS * 4;                 // MFMA groups per chunk
                         const int gq = g * G * 4 + q;
 #pragma unroll
@@ -218,7 +221,7 @@ void lin_split_kernel(const LinSplitParams p) {
     }
     GS_MARK(9);
 #pragma unroll
-    for (int n = 0; n < 64; ++n) store_one(done, p.chunks - 1, n);
+    for (int n = 0; n < 64; ++n) store_one(done, c1 - 1, n);
     GS_MARK(10);
 }
 
@@ -536,6 +539,9 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
                     float v = acc[tt][ot][i] + bias;
                     if (p.accum) v += *dst;
                     if (p.relu) v = fmaxf(v, 0.f);
+#ifdef GS_NOSTORE
+                    if (v == 12345.678f)
+#endif
                     *dst = v;
                 }
             }
@@ -587,7 +593,11 @@ PDA_API int pda_linear_split(const float* x, const void* wf, const float* bias, 
 #ifdef GS_PROFILE
     p.dbg = (unsigned long long*)bias; p.bias = nullptr;
 #endif
-    const dim3 grid((unsigned)pda::divup64(tokens, 128)), block(256);
+    // one workgroup walks all chunks of its 128 tokens (X read once) unless that leaves most of the chip idle
+    const int64_t tiles = pda::divup64(tokens, 128);
+    const int want = tiles >= 192 ? 1 : (int)pda::divup64(256, tiles);
+    p.cpb = pda::divup(p.chunks, want < p.chunks ? want : p.chunks);
+    const dim3 grid((unsigned)tiles, (unsigned)pda::divup(p.chunks, p.cpb)), block(256);
     const hipStream_t s = (hipStream_t)stream;
     switch (k / 16) {
 #define PDA_GS_CASE(KS) case KS: hipLaunchKernelGGL((pda::lin_split_kernel<KS>), grid, block, 0, s, p); break

@@ -17,7 +17,9 @@ def _rel_err(y, x, w, bias):
 
 
 @pytest.mark.parametrize("T,K,N", [(1, 32, 128), (127, 64, 128), (1000, 96, 256), (4099, 128, 384), (20000, 256, 512),
-                                   (33000, 512, 512), (5000, 384, 1536), (2048, 512, 2048)])
+                                   (33000, 512, 512), (5000, 384, 1536), (2048, 512, 2048),
+                                   # few tokens: the output chunks spread over blockIdx.y (2 chunks per workgroup; a ragged last group)
+                                   (6600, 192, 1280), (16384, 128, 384), (4096, 256, 256)])
 def test_split_gemm_has_f32_accuracy(T, K, N):
     from pdanet_amd import pointnet2_batch_cuda as ext
     g = torch.Generator("cuda").manual_seed(T + K + N)
