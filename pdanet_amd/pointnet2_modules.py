@@ -19,6 +19,8 @@ What is done differently (results unchanged):
 """
 from typing import List
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -81,6 +83,7 @@ def _bn_lastdim(bn, x):
     return y.permute(0, 2, 3, 1).reshape(shp)
 
 
+PLAN_OVERLAP = os.environ.get("PDA_PLAN_OVERLAP", "1") != "0"   # PDA layer: work that needs no token count goes ahead of the host's wait for it
 FUSED_BN_RELU = True   # csrc/bn_relu.hip instead of F.batch_norm + F.relu in training mode
 FUSED_TRANSFORMER_BLOCK = True   # the whole encoder layer as one autograd node (pointnet2_utils.TransformerBlock)
 FUSED_GEOMETRY = True   # one kernel for the PDA grouper's density / direction / position-encoding input
@@ -672,6 +675,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         # sampling side stream when the centres depend on coordinates only (`prequery`, whose event the caller has waited
         # for on this stream and on the host), otherwise here with ONE host synchronisation for the layer
         plans = [None] * len(self.groupers)
+        pending = None
         if prequery is not None:
             idxs = prequery['idxs']
             if prequery['parts'] is not None and self.ragged_capable(features):
@@ -679,12 +683,24 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         else:
             idxs = self._ball_queries(xyz, new_xyz)
             if self.ragged_capable(features):
-                plans = pointnet2_utils.ragged_plans(idxs)
-        plans = [p if p is not None and p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in plans]
+                # The token counts size the encoder's tensors, so the host has to read them -- but not by draining the
+                # stream: the counts go to pinned memory behind the plan kernels, an event marks that copy, and everything
+                # of the layer that does not need them (geometry, DensityNet, the centre MLPs of every scale) is enqueued
+                # BEFORE the host waits for the event.  The host is several ms ahead of the device when it gets here; a
+                # blocking read left the device with an empty queue behind the plan kernel and ~100 small launches to
+                # wait for (1.3 ms idle per step, tools/step_gaps.py).
+                parts, totals = pointnet2_utils.ragged_plan_parts(idxs)
+                pinned = torch.empty((len(parts),), dtype=torch.int32, pin_memory=True)
+                pinned.copy_(totals, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                if not PLAN_OVERLAP:
+                    ev.synchronize()
+                pending = (parts, pinned, ev)
         feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
         global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)
         centre = new_xyz.unsqueeze(2)                                         # (B, M, 1, 3)
-        outs = []
+        pre = []
         for i in range(len(self.groupers)):
             r, ns = self.groupers[i].radius, self.nsamples[i]
             fused_geo = (FUSED_GEOMETRY and xyz.is_cuda and xyz.dtype == torch.float32 and ns <= 64 and ns & (ns - 1) == 0
@@ -716,20 +732,35 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                     else:
                         dscale = _bn_relu_lastdim(bn, pointnet2_utils.linear(dscale, conv.weight.flatten(1), conv.bias))
             glob = _mlp_lastdim(self.global_mlps[i], global_in)               # (B, M, C)
+            pre.append((rppe, dscale, glob))
+        if pending is not None:
+            parts, pinned, ev = pending
+            ev.synchronize()
+            plans = pointnet2_utils.ragged_plans_from(parts, pinned.tolist())
+        plans = [p if p is not None and p.fraction <= pointnet2_utils.RAGGED_MAX_FRACTION else None for p in plans]
+        # the scale with the most tokens first: its long kernels give the host the time to enqueue the other scales' short ones
+        outs = [None] * len(self.groupers)
+        order = sorted(range(len(self.groupers)), key=lambda i: -(plans[i].tokens if plans[i] is not None else npoint * self.nsamples[i] * B))
+        if not PLAN_OVERLAP:
+            order = list(range(len(self.groupers)))
+        for i in order:
+            ns = self.nsamples[i]
+            rppe, dscale, glob = pre[i]
+            pre[i] = None
             if (plans[i] is not None and feats_pm.shape[-1] in (16, 32, 64, 128, 256) and FUSED_BN_RELU
                     and pointnet2_utils.FUSED_ASSEMBLE and pointnet2_utils.position_mlp_ragged_supported(self.position_mlp[i], rppe)):
                 # position MLP, token assembly and encoder all on the distinct tokens
                 rppe_c = pointnet2_utils.position_mlp_ragged(self.position_mlp[i], rppe, plans[i])        # (U, C)
                 x = pointnet2_utils.AssembleTokensRagged.apply(rppe_c, dscale, feats_pm, idxs[i], glob, plans[i])
                 x = pointnet2_utils.ragged_transformer_block(self.Local_pointformer[i], x, plans[i]).view(B, npoint, -1)
-                outs.append(_mlp_lastdim(self.fin_conv[i], x))
+                outs[i] = _mlp_lastdim(self.fin_conv[i], x)
                 continue
             rppe = _mlp_lastdim(self.position_mlp[i], rppe)                   # (B, M, ns, C)
             if plans[i] is not None and pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
                 # the encoder on the distinct tokens only (csrc/ragged.hip): x (U, 4C) -> (B, M, 4C)
                 x = pointnet2_utils.AssembleTokensRagged.apply(rppe, dscale, feats_pm, idxs[i], glob, plans[i])
                 x = pointnet2_utils.ragged_transformer_block(self.Local_pointformer[i], x, plans[i]).view(B, npoint, -1)
-                outs.append(_mlp_lastdim(self.fin_conv[i], x))
+                outs[i] = _mlp_lastdim(self.fin_conv[i], x)
                 continue
             if pointnet2_utils.AssembleTokens.supported(rppe, feats_pm):
                 x = pointnet2_utils.AssembleTokens.apply(rppe, dscale, feats_pm, idxs[i], glob)   # (B, M, ns, 4C)
@@ -739,7 +770,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
             D = x.shape[-1]
             # encoder layer + max over nsample (:931)
             x = _transformer_batch_first(self.Local_pointformer[i], x.view(B * npoint, ns, D), pool=True).view(B, npoint, D)
-            outs.append(_mlp_lastdim(self.fin_conv[i], x))                    # (B, M, mlp[-1])
+            outs[i] = _mlp_lastdim(self.fin_conv[i], x)                       # (B, M, mlp[-1])
         new_features = torch.cat(outs, dim=-1)                                # (B, M, sum)
         if self.aggregation_layer is not None:
             new_features = _mlp_lastdim(self.aggregation_layer, new_features)
