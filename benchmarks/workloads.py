@@ -17,6 +17,10 @@ DEFAULT = "detector_train"
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 F32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: f32-input MFMA (v_mfma_f32_32x32x2_f32) = the f32 vector peak
 BF16_MFMA_PEAK_TF = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (v_mfma_f32_32x32x16_bf16), no sparsity
+# What a kernel of nothing but v_mfma_f32_32x32x16_bf16 on register operands holds on random normal data, two waves per SIMD
+# (tools/microbench/mfma_sustained.hip, profiles/r03_mfma_sustained.txt: 1813 TFLOP/s = a 1.73 GHz matrix clock; 2350 on
+# zeros): the power-managed ceiling under `frac`'s nominal peak.  Reported beside `frac`, never instead of it.
+BF16_MFMA_SUSTAINED_TF = 1813.0
 SPLIT_PRODUCTS = 6          # csrc/split_bf16.h: an f32 product block = 6 bf16 MFMA blocks (3-term operands, 6 of 9 products)
 # plain (non-packed) VALU lane-operations per second: 256 CUs x 4 SIMDs x 16 lanes x 2.4 GHz.  A ball-query
 # distance test is 7 VALU instructions (3 sub, 1 mul, 2 fma, 1 compare), none of them packable without losing
@@ -213,6 +217,7 @@ class KernelTimers:
         return {"kernel": "gemm_split_wide_kernel / lin_split_kernel (SA group MLP, training form: %d launches per step, "
                           "forward + input gradient)" % (ns_ // steps),
                 "bound": "mfma", "achieved": work, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": work / BF16_MFMA_PEAK_TF,
+                "sustained_mfma_only_kernel": BF16_MFMA_SUSTAINED_TF, "frac_of_sustained": work / BF16_MFMA_SUSTAINED_TF,
                 "achieved_f32_equiv": fs / ts / 1e12, "peak_f32_input_mfma": F32_MFMA_PEAK_TF,
                 "traffic": None, "ms_per_step": ts / steps * 1e3, "gflop_per_step": fs / steps / 1e9,
                 "mfma_busy_pmc": None if util is None else round(util["mfma_util"], 4), "f32_mfma_part": f32_part,
@@ -255,6 +260,7 @@ class KernelTimers:
         if split:
             work = SPLIT_PRODUCTS * f32_equiv
             out.update(achieved=work, peak=BF16_MFMA_PEAK_TF, unit="TFLOP/s", frac=work / BF16_MFMA_PEAK_TF,
+                       sustained_mfma_only_kernel=BF16_MFMA_SUSTAINED_TF, frac_of_sustained=work / BF16_MFMA_SUSTAINED_TF,
                        achieved_f32_equiv=f32_equiv, peak_f32_input_mfma=F32_MFMA_PEAK_TF)
             note = ("three-term bf16 split of both operands, six v_mfma_f32_32x32x16_bf16 per f32 product block (f32 accuracy): "
                     "achieved = 6 x algorithmic flops / time = the bf16 MFMA work really issued, peak = dense bf16 MFMA; "
@@ -521,6 +527,7 @@ class BackboneInferWorkload(BackboneWorkload):
         work = SPLIT_PRODUCTS * fl / t / 1e12
         return {"kernel": "sa_wide_scale_infer: sa_point_gather_kernel + gemm_split_wide_kernel / lin_split_kernel (+ max-pool), %d scales per step" % (len(ev) // steps),
                 "bound": "mfma", "achieved": work, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": work / BF16_MFMA_PEAK_TF,
+                "sustained_mfma_only_kernel": BF16_MFMA_SUSTAINED_TF, "frac_of_sustained": work / BF16_MFMA_SUSTAINED_TF,
                 "achieved_f32_equiv": fl / t / 1e12, "peak_f32_input_mfma": F32_MFMA_PEAK_TF, "traffic": None,
                 "ms_per_step": t / steps * 1e3, "gflop_per_step": fl / steps / 1e9,
                 "note": "flops of layers 2 and 3 only (the first layer is a per-point projection of 0.5 GFLOP + a row gather); time of "
