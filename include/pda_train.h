@@ -102,6 +102,35 @@ int64_t pda_linear_wgrad_scratch_bytes(int64_t tokens, int in_features, int out_
 int pda_linear_wgrad_form(int64_t tokens, int in_features, int out_features);
 int pda_linear_wgrad(const float *x, const float *grad_out, float *grad_weight, float *grad_bias,
                      void *scratch, int64_t tokens, int in_features, int out_features, pda_stream_t stream);
+/* The same with x = the PRE-BatchNorm tensor of the layer: the weight gradient is taken against relu(bn(x)) formed in the
+ * operand load (x_mean_invstd (2, in) = mean | invstd of the batch, x_gamma, x_beta (in)); the layer's activation need not
+ * exist in memory.  Only shapes with pda_linear_wgrad_form == 2; otherwise PDA_ERR_UNSUPPORTED. */
+int pda_linear_wgrad_bn(const float *x, const float *grad_out, float *grad_weight, float *grad_bias, void *scratch,
+                        int64_t tokens, int in_features, int out_features, const float *x_mean_invstd,
+                        const float *x_gamma, const float *x_beta, pda_stream_t stream);
+
+/* ---- a [conv1x1 -> BatchNorm(batch statistics) -> ReLU] chain with the BatchNorm passes folded into the contractions
+ * (MI355X extension; the group MLP of pointnet2_modules.py:1657-1662 in training).
+ * pda_gemm_split_bn: y (tokens, n_out) = X' W^T on the 256 x 256 tile split-bf16 kernel (wf = pda_linear_split_pack planes,
+ * K a multiple of 32 <= 1024), where X' = x, or relu(bn(x)) when in_mean_invstd (2, K) / in_gamma / in_beta (K) are given.
+ * stats_mode 1: partial [pda_gemm_split_bn_tiles(tokens)][2][n_out] doubles = per-column sum and sum of squares of y over each
+ * tile of 256 tokens (the statistics pass of the BatchNorm behind this contraction; finish with pda_bn_finalize_fwd).
+ * Fixed summation order. */
+int64_t pda_gemm_split_bn_tiles(int64_t tokens);
+int pda_gemm_split_bn(const float *x, const void *wf, float *y, int64_t tokens, int k, int n_out,
+                      const float *in_mean_invstd, const float *in_gamma, const float *in_beta, int stats_mode,
+                      double *partial, pda_stream_t stream);
+/* The passes of pda_bn_relu_fwd / pda_bn_relu_max_pool_fwd one at a time.  pda_bn_stats_fwd: statistics of x only
+ * (mean_invstd (2, C), running statistics updated); scratch: pda_bn_relu_scratch_bytes(c).  pda_bn_finalize_fwd: the same
+ * from `nblocks` rows of per-block sums [nblocks][2][C] (count = the number of rows they cover).
+ * pda_bn_relu_max_pool_apply: normalise + ReLU + max over ns with given statistics. */
+int pda_bn_stats_fwd(const float *x, float *running_mean, float *running_var, float *mean_invstd, void *scratch,
+                     int64_t rows, int c, float eps, float momentum, pda_stream_t stream);
+int pda_bn_finalize_fwd(const double *partial, int nblocks, int c, int64_t count, float eps, float momentum,
+                        float *mean_invstd, float *running_mean, float *running_var, pda_stream_t stream);
+int pda_bn_relu_max_pool_apply(const float *x, const float *gamma, const float *beta, const float *mean_invstd,
+                               float *out, uint8_t *arg, int64_t groups, int ns, int c, pda_stream_t stream);
+
 /* Dense-bf16 mode: the bias gradient alone, column sums of the bf16 gradient g (rows, cols) -> out (cols) fp32 (fixed
  * summation order).  cols: multiple of 8, <= 2048; scratch: pda_colsum_scratch_bytes(cols) bytes. */
 int64_t pda_colsum_scratch_bytes(int cols);

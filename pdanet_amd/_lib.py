@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -80,6 +80,12 @@ SIGNATURES = {
     "pda_linear_wgrad_scratch_bytes": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad_form": [ctypes.c_int64, _i, _i],
     "pda_linear_wgrad": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
+    "pda_linear_wgrad_bn": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp, _vp, _vp, _vp],
+    "pda_gemm_split_bn_tiles": [ctypes.c_int64],
+    "pda_gemm_split_bn": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
+    "pda_bn_stats_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
+    "pda_bn_finalize_fwd": [_vp, _i, _i, ctypes.c_int64, _f, _f, _vp, _vp, _vp, _vp],
+    "pda_bn_relu_max_pool_apply": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_colsum_scratch_bytes": [_i],
     "pda_colsum_bf16": [_vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_assemble_tokens": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
@@ -164,6 +170,7 @@ def load():
     lib.pda_linear_wgrad_scratch_bytes.restype = ctypes.c_int64
     lib.pda_linear_split_packed_bytes.restype = ctypes.c_int64
     lib.pda_colsum_scratch_bytes.restype = ctypes.c_int64
+    lib.pda_gemm_split_bn_tiles.restype = ctypes.c_int64
     lib.pda_densitynet_scratch_bytes.restype = ctypes.c_int64
     lib.pda_sa_small_train_workspace_bytes.restype = ctypes.c_int64
     lib.pda_sa_xyz_grad_scratch_bytes.restype = ctypes.c_int64

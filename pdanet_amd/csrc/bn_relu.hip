@@ -447,3 +447,46 @@ PDA_API int pda_bn_relu_max_pool_bwd(const void* x, int x_is_bf16, const float* 
     return pda::launch_bn_relu_pool_bwd<float>((const float*)x, grad_out, arg, gamma, beta, mean_invstd, (float*)grad_x, grad_gamma, grad_beta,
                                                scratch, groups, ns, c, (hipStream_t)stream, what);
 }
+
+// ---- the passes one at a time: chains whose statistics come out of a GEMM's epilogue (pda_gemm_split_bn, csrc/gemm_split.hip) and
+// whose normalised activations are only ever formed in a consumer's operand load --------------------------------------------
+PDA_API int pda_bn_stats_fwd(const float* x, float* running_mean, float* running_var, float* mean_invstd, void* scratch, int64_t rows, int c,
+                             float eps, float momentum, pda_stream_t stream) {
+    const char* what = "pda_bn_stats_fwd";
+    pda::BnShape s;
+    if (int rc = pda::bn_shape(rows, c, s, what)) return rc;
+    PDA_REQUIRE(x && mean_invstd && scratch && pda::bn_aligned(x) && ((uintptr_t)mean_invstd & 15) == 0, "%s: null or misaligned pointer", what);
+    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "%s: running_mean/var must come together", what);
+    const int grid = pda::bn_grid(s);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL((pda::bn_reduce_kernel<false, float, float>), dim3(grid), dim3(256), 0, st, x, (const float*)nullptr, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, (double*)scratch, s);
+    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, st, (const double*)scratch, grid, c, s.count, eps, momentum,
+                       mean_invstd, running_mean, running_var);
+    return pda::check_launch(what);
+}
+
+PDA_API int pda_bn_finalize_fwd(const double* partial, int nblocks, int c, int64_t count, float eps, float momentum, float* mean_invstd,
+                                float* running_mean, float* running_var, pda_stream_t stream) {
+    PDA_REQUIRE(partial && mean_invstd && nblocks >= 1 && c >= 1 && count >= 1, "pda_bn_finalize_fwd: bad argument");
+    PDA_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "pda_bn_finalize_fwd: running_mean/var must come together");
+    hipLaunchKernelGGL(pda::bn_finalize_fwd_kernel, dim3(pda::divup(c, 32)), dim3(512), 0, (hipStream_t)stream, partial, nblocks, c, count, eps,
+                       momentum, mean_invstd, running_mean, running_var);
+    return pda::check_launch("pda_bn_finalize_fwd");
+}
+
+// the second pass of pda_bn_relu_max_pool_fwd alone (statistics given)
+PDA_API int pda_bn_relu_max_pool_apply(const float* x, const float* gamma, const float* beta, const float* mean_invstd, float* out, uint8_t* arg,
+                                       int64_t groups, int ns, int c, pda_stream_t stream) {
+    const char* what = "pda_bn_relu_max_pool_apply";
+    PDA_REQUIRE(groups >= 1 && ns >= 1 && ns <= 255, "%s: groups=%lld ns=%d (1..255)", what, (long long)groups, ns);
+    pda::BnShape s;
+    if (int rc = pda::bn_shape(groups * ns, c, s, what)) return rc;
+    s.ns = ns;
+    PDA_REQUIRE(x && gamma && beta && out && arg && mean_invstd, "%s: null pointer", what);
+    PDA_REQUIRE(pda::bn_aligned(x) && (((uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta | (uintptr_t)mean_invstd) & 15) == 0 &&
+                    ((uintptr_t)arg & 3) == 0, "%s: alignment", what);
+    hipLaunchKernelGGL(pda::bn_apply_pool_kernel<float>, dim3((unsigned)pda::divup64(groups * s.cg, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       mean_invstd, gamma, beta, out, arg, groups, s);
+    return pda::check_launch(what);
+}

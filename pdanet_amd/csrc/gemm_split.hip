@@ -242,6 +242,11 @@ struct GemmSplitParams {
     float* y;               // (T, N) row-major
     int64_t tokens;
     int k, n_out, chunks, ksteps, relu, accum;
+    // BatchNorm fused on either side (gemm_split_wide_kernel<PRO, EPI>, pda_gemm_split_bn):
+    const float* in_mi;     // PRO: (2, K) mean | invstd of the INPUT channels; X is read as relu((x - mean) * invstd * gamma + beta)
+    const float* in_g;      //      (K) gamma
+    const float* in_b;      //      (K) beta
+    double* partial;        // EPI: [token tile][2][n_out] per-column sum / sum of squares of this launch's output
 };
 
 constexpr int GT_XCHUNKS = 128 * 4;                  // uint4 per X tile (128 rows x 64 bytes)
@@ -380,6 +385,15 @@ void gemm_split_kernel(const GemmSplitParams p) {
 // slower than this form: the output stores are not what holds it back.
 typedef uint32_t gp_u32x4 __attribute__((ext_vector_type(4)));
 
+// PRO = 1: the X operand is the PRE-BatchNorm tensor of the layer before; the producer role applies that layer's training-mode
+//   BatchNorm + ReLU (the expression of bn_apply_kernel, csrc/bn_relu.hip, bit for bit) to the eight values it is about to
+//   split, so relu(bn(x)) never exists in HBM.  The four per-channel constants sit in LDS behind the plane buffers.
+// EPI = 1: besides storing Y, the workgroup writes the per-column sum and sum of squares of its 256 token rows (double,
+//   fixed order: 32 rows per lane, the two half-waves, then the four token-waves) -- the statistics pass of the BatchNorm
+//   that follows, without reading Y again.  (The reduction pass of the BatchNorm BACKWARD in the epilogue of the
+//   input-gradient GEMM, z read tile by tile next to the stores, was measured and removed: 131072 x 512 -> 512 went from
+//   0.36 to 0.60 ms, the standalone pass costs 0.10.)
+template <int PRO, int EPI>
 __global__ __launch_bounds__(512, 1)
 void gemm_split_wide_kernel(const GemmSplitParams p) {
     constexpr int TW = 4;                           // token-waves (x 2 output-waves)
@@ -415,6 +429,14 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
     };
     uint4* const my_x = gp_planes + w * 192 + lane;                     // + buffer * TILE_U4 + plane * 64
     uint4* const my_w = gp_planes + XF * 192 + (NP * w) * 64 + lane;    // + buffer * TILE_U4 + e * 64
+    // PRO: {mean, invstd, gamma, beta} of input channel k at cst[k]
+    float4* const cst = reinterpret_cast<float4*>(gp_planes + 2 * TILE_U4);
+    if constexpr (PRO) {
+        for (int k = tid; k < p.k; k += 512) cst[k] = make_float4(p.in_mi[k], p.in_mi[p.k + k], p.in_g[k], p.in_b[k]);
+        __syncthreads();
+    }
+    auto bnrelu = [&](float x, const float4& c) { return fmaxf((x - c.x) * c.y * c.z + c.w, 0.f); };
+    const float4* const my_cst = cst + 8 * h;                           // + 16 * step + j
     gs_f32x16 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -456,11 +478,15 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
         read_b(1);
         uint32_t ph[4], pm[4], pl[4];
         const float xv[8] = {xa[0].x, xa[0].y, xa[0].z, xa[0].w, xa[1].x, xa[1].y, xa[1].z, xa[1].w};
+        const int kn = st + 1 < p.ksteps ? st + 1 : p.ksteps - 1;        // the step whose planes are made here
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
+            float4 c0, c1;
+            if constexpr (PRO) { c0 = my_cst[16 * kn + 2 * q]; c1 = my_cst[16 * kn + 2 * q + 1]; }
             mfma3(An, 0, q);
             __builtin_amdgcn_sched_barrier(0);
-            split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
+            if constexpr (PRO) split2(bnrelu(xv[2 * q], c0), bnrelu(xv[2 * q + 1], c1), ph[q], pm[q], pl[q]);
+            else split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
             __builtin_amdgcn_sched_barrier(0);
         }
         my_x[ob] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
@@ -507,7 +533,10 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
         uint32_t ph[4], pm[4], pl[4];
         const float xv[8] = {x1[0].x, x1[0].y, x1[0].z, x1[0].w, x1[1].x, x1[1].y, x1[1].z, x1[1].w};
 #pragma unroll
-        for (int q = 0; q < 4; ++q) split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
+        for (int q = 0; q < 4; ++q) {
+            if constexpr (PRO) split2(bnrelu(xv[2 * q], my_cst[2 * q]), bnrelu(xv[2 * q + 1], my_cst[2 * q + 1]), ph[q], pm[q], pl[q]);
+            else split2(xv[2 * q], xv[2 * q + 1], ph[q], pm[q], pl[q]);
+        }
         my_x[0] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         my_x[64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         my_x[128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
@@ -523,8 +552,10 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
     for (int e = 0; e < 12; ++e)                   // output block 3 of the last step
         acc[e & 1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[e & 1][PA[e >> 1]], Bf[1][PB[e >> 1]], acc[e & 1][3], 0, 0, 0);
     // rows of a 32 x 32 tile: token (i & 3) + 8 (i >> 2) + 4 h; column: output (2 ncb + wo) * 128 + ot * 32 + r
+    double cs1[4], cs2[4];                          // EPI: this lane's column sums (one column per output block)
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
+        cs1[ot] = 0; cs2[ot] = 0;
         const int col = (2 * ncb + wo) * 128 + ot * 32 + r;
         if (col >= p.n_out) continue;
         const float bias = p.bias ? p.bias[col] : 0.f;
@@ -543,7 +574,32 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
                     if (v == 12345.678f)
 #endif
                     *dst = v;
+                    if constexpr (EPI == 1) { cs1[ot] += v; cs2[ot] += (double)v * v; }
                 }
+            }
+        }
+    }
+    if constexpr (EPI != 0) {
+        // lanes r and r + 32 hold the same columns; the four token-waves of an output-wave too: LDS [wt][column 0..255][2]
+        double* red = reinterpret_cast<double*>(gp_planes);
+        __syncthreads();                            // every wave is done with the plane buffers
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const double a = cs1[ot] + __shfl_xor(cs1[ot], 32), b = cs2[ot] + __shfl_xor(cs2[ot], 32);
+            if (h == 0) {
+                const int cl = wo * 128 + ot * 32 + r;
+                red[(wt * 256 + cl) * 2] = a; red[(wt * 256 + cl) * 2 + 1] = b;
+            }
+        }
+        __syncthreads();
+        if (tid < 256) {
+            const int col = 2 * ncb * 128 + tid;
+            if (col < p.n_out) {
+                double a = 0, b = 0;
+#pragma unroll
+                for (int q = 0; q < TW; ++q) { a += red[(q * 256 + tid) * 2]; b += red[(q * 256 + tid) * 2 + 1]; }
+                double* pp = p.partial + (size_t)(blockIdx.x / (unsigned)wide_chunks) * 2 * p.n_out;
+                pp[col] = a; pp[p.n_out + col] = b;
             }
         }
     }
@@ -637,14 +693,51 @@ PDA_API int pda_gemm_split(const float* x, const void* wf, const float* bias, fl
     const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
     if (force == 256 || (force != 128 && wide_blocks >= 200 && (p.chunks % 2 == 0 || p.chunks >= 5))) {
         static pda::PerDevice<bool> lds_ok;
-        const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+        const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel<0, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                                                    2 * pda::GW_TILE_U4 * 16) == hipSuccess; });
         if (ok) {
-            hipLaunchKernelGGL(pda::gemm_split_wide_kernel, dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16,
+            hipLaunchKernelGGL((pda::gemm_split_wide_kernel<0, 0>), dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16,
                                (hipStream_t)stream, p);
             return pda::check_launch("pda_gemm_split");
         }
     }
     hipLaunchKernelGGL(pda::gemm_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p);
     return pda::check_launch("pda_gemm_split");
+}
+
+// Y = relu(bn_in(X)) W^T (in_* given) or X W^T, with the statistics pass of the BatchNorm behind it in the epilogue
+// (stats_mode 1).  Always the 256 x 256 tile kernel: partial holds pda_gemm_split_bn_tiles(tokens) x 2 x n_out doubles.
+PDA_API int64_t pda_gemm_split_bn_tiles(int64_t tokens) { return tokens > 0 ? pda::divup64(tokens, 256) : 0; }
+
+PDA_API int pda_gemm_split_bn(const float* x, const void* wf, float* y, int64_t tokens, int k, int n_out, const float* in_mean_invstd,
+                              const float* in_gamma, const float* in_beta, int stats_mode, double* partial, pda_stream_t stream) {
+    PDA_REQUIRE(tokens >= 1 && k > 0 && n_out > 0, "pda_gemm_split_bn: bad size");
+    PDA_REQUIRE(x && wf && y && (((uintptr_t)x | (uintptr_t)wf) & 15) == 0, "pda_gemm_split_bn: null or misaligned pointer");
+    const bool pro = in_mean_invstd != nullptr;
+    PDA_REQUIRE(pro == (in_gamma != nullptr) && pro == (in_beta != nullptr), "pda_gemm_split_bn: the input BatchNorm needs mean_invstd, gamma and beta");
+    PDA_REQUIRE(stats_mode >= 0 && stats_mode <= 1 && (stats_mode == 0 || partial), "pda_gemm_split_bn: stats_mode=%d (0 or 1; 1 needs `partial`)", stats_mode);
+    if (k % 32 != 0 || k > 1024) {
+        pda::set_error("pda_gemm_split_bn: no kernel built for K=%d (a multiple of 32, <= 1024)", k);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::GemmSplitParams p{};
+    p.x = x; p.wf = (const uint4*)wf; p.y = y; p.tokens = tokens; p.k = k; p.n_out = n_out;
+    p.chunks = pda::divup(n_out, 128); p.ksteps = k / 16;
+    p.in_mi = in_mean_invstd; p.in_g = in_gamma; p.in_b = in_beta; p.partial = partial;
+    const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
+    PDA_REQUIRE(wide_blocks < (1ll << 31), "pda_gemm_split_bn: too many tiles");
+    const int lds = 2 * pda::GW_TILE_U4 * 16 + (pro ? k * 16 : 0);
+    const void* fn;
+    if (pro && stats_mode == 1) fn = (const void*)pda::gemm_split_wide_kernel<1, 1>;
+    else if (pro && stats_mode == 0) fn = (const void*)pda::gemm_split_wide_kernel<1, 0>;
+    else if (stats_mode == 1) fn = (const void*)pda::gemm_split_wide_kernel<0, 1>;
+    else fn = (const void*)pda::gemm_split_wide_kernel<0, 0>;
+    static pda::PerDevice<bool> lds_ok[4];
+    const bool ok = lds_ok[(pro ? 2 : 0) + stats_mode].get([fn] {
+        return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pda::GW_TILE_U4 * 16 + 1024 * 16) == hipSuccess; });
+    PDA_REQUIRE(ok, "pda_gemm_split_bn: dynamic LDS refused");
+    void* args[] = {(void*)&p};
+    PDA_REQUIRE(hipLaunchKernel(fn, dim3((unsigned)wide_blocks), dim3(512), args, lds, (hipStream_t)stream) == hipSuccess,
+                "pda_gemm_split_bn: launch failed");
+    return pda::check_launch("pda_gemm_split_bn");
 }

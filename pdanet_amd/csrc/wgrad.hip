@@ -204,10 +204,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const float* __restrict__ X,
 #endif
 constexpr int WSP_TILE_U4 = 2 * 8 * 3 * 64;      // uint4 per plane buffer: 48 KB
 
+// XBN: X is the PRE-BatchNorm tensor of the layer; its training-mode BatchNorm + ReLU (bn_apply_kernel's expression,
+// csrc/bn_relu.hip) is applied to the eight values of a lane's column right before they are split -- the layer's activation
+// is never read from (or written to) HBM.  Rows behind the slice read as 0 in both operands, so what the transform makes
+// of a zero row of X meets a zero row of G.
+template <bool XBN>
 __global__ __launch_bounds__(512, 1)
 void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G, float* __restrict__ part_w,
                         float* __restrict__ part_b, int64_t T, int M, int N, int tiles_m, int tiles_n, int S, int64_t KS,
-                        int nblocks) {
+                        int nblocks, const float* __restrict__ x_mi, const float* __restrict__ x_g, const float* __restrict__ x_b) {
     extern __shared__ uint4 wsp_planes[];        // 2 * WSP_TILE_U4
     const int per_xcd = (nblocks + 7) / 8;       // workgroups of one slice on one XCD (they read the same rows)
     const int logical = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
@@ -236,6 +241,9 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
 #pragma unroll
         for (int j = 0; j < 8; ++j) load1(st, j, g, x);
     };
+    float xmu = 0.f, xis = 0.f, xga = 0.f, xbe = 0.f;       // XBN: the constants of this lane's column of X
+    if constexpr (XBN) { const int m = m0 + 32 * w + c; xmu = x_mi[m]; xis = x_mi[M + m]; xga = x_g[m]; xbe = x_b[m]; }
+    auto xt = [&](float v) { return XBN ? fmaxf((v - xmu) * xis * xga + xbe, 0.f) : v; };
     float bsum = 0.f;
     const bool do_bias = part_b && m0 == 0;
     gs_f32x16 acc[2][4];
@@ -312,7 +320,7 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
 #if WSP_ABL == 1
             ph[q] = __float_as_uint(xa[2 * q]); pm[q] = __float_as_uint(xa[2 * q + 1]); pl[q] = ph[q] ^ pm[q];
 #else
-            split2(xa[2 * q], xa[2 * q + 1], ph[q], pm[q], pl[q]);
+            split2(xt(xa[2 * q]), xt(xa[2 * q + 1]), ph[q], pm[q], pl[q]);
 #endif
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -340,7 +348,7 @@ void wgrad_split_kernel(const float* __restrict__ X, const float* __restrict__ G
         out[64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         out[128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) split2(x[2 * q], x[2 * q + 1], ph[q], pm[q], pl[q]);
+        for (int q = 0; q < 4; ++q) split2(xt(x[2 * q]), xt(x[2 * q + 1]), ph[q], pm[q], pl[q]);
         out[8 * 192] = make_uint4(ph[0], ph[1], ph[2], ph[3]);
         out[8 * 192 + 64] = make_uint4(pm[0], pm[1], pm[2], pm[3]);
         out[8 * 192 + 128] = make_uint4(pl[0], pl[1], pl[2], pl[3]);
@@ -571,8 +579,31 @@ PDA_API int pda_linear_wgrad_form(int64_t tokens, int in_features, int out_featu
     return pda::wgrad_use_split(tokens, in_features, out_features) ? 2 : 0;
 }
 
+namespace pda {
+static int linear_wgrad(const float* x, const float* grad_out, float* grad_weight, float* grad_bias, void* scratch, int64_t tokens,
+                        int in_features, int out_features, pda_stream_t stream, const float* x_mi, const float* x_g, const float* x_b);
+}
+
 PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_weight, float* grad_bias, void* scratch,
                              int64_t tokens, int in_features, int out_features, pda_stream_t stream) {
+    return pda::linear_wgrad(x, grad_out, grad_weight, grad_bias, scratch, tokens, in_features, out_features, stream, nullptr, nullptr, nullptr);
+}
+
+// dW = dY^T relu(bn(x)): x is the PRE-BatchNorm tensor, (x_mean_invstd, x_gamma, x_beta) the layer's batch statistics and
+// affine parameters.  Only the split-bf16 form has the transform in its operand path (pda_linear_wgrad_form == 2).
+PDA_API int pda_linear_wgrad_bn(const float* x, const float* grad_out, float* grad_weight, float* grad_bias, void* scratch,
+                                int64_t tokens, int in_features, int out_features, const float* x_mean_invstd, const float* x_gamma,
+                                const float* x_beta, pda_stream_t stream) {
+    PDA_REQUIRE(x_mean_invstd && x_gamma && x_beta, "pda_linear_wgrad_bn: null pointer");
+    if (pda_linear_wgrad_form(tokens, in_features, out_features) != 2) {
+        pda::set_error("pda_linear_wgrad_bn: tokens=%lld in=%d out=%d does not run on the split form", (long long)tokens, in_features, out_features);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    return pda::linear_wgrad(x, grad_out, grad_weight, grad_bias, scratch, tokens, in_features, out_features, stream, x_mean_invstd, x_gamma, x_beta);
+}
+
+int pda::linear_wgrad(const float* x, const float* grad_out, float* grad_weight, float* grad_bias, void* scratch, int64_t tokens,
+                             int in_features, int out_features, pda_stream_t stream, const float* x_mi, const float* x_g, const float* x_b) {
     const int M = in_features, N = out_features;
     PDA_REQUIRE(tokens >= 1 && M >= 4 && N >= 4 && (M & 3) == 0 && (N & 3) == 0,
                 "pda_linear_wgrad: tokens=%lld in=%d out=%d (features must be multiples of 4)", (long long)tokens, M, N);
@@ -603,11 +634,16 @@ PDA_API int pda_linear_wgrad(const float* x, const float* grad_out, float* grad_
         float* part_w = (float*)scratch;
         float* part_b = part_w + (size_t)S * N * M;
         static pda::PerDevice<bool> lds_ok;
-        const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::wgrad_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                                   2 * pda::WSP_TILE_U4 * 16) == hipSuccess; });
+        const bool ok = lds_ok.get([] {
+            return hipFuncSetAttribute((const void*)pda::wgrad_split_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pda::WSP_TILE_U4 * 16) == hipSuccess &&
+                   hipFuncSetAttribute((const void*)pda::wgrad_split_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * pda::WSP_TILE_U4 * 16) == hipSuccess; });
         PDA_REQUIRE(ok, "pda_linear_wgrad: %d bytes of dynamic LDS refused", 2 * pda::WSP_TILE_U4 * 16);
-        hipLaunchKernelGGL(pda::wgrad_split_kernel, dim3(pda::divup(nblocks, 8) * 8), dim3(512), 2 * pda::WSP_TILE_U4 * 16, st,
-                           x, grad_out, part_w, grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks);
+        if (x_mi)
+            hipLaunchKernelGGL(pda::wgrad_split_kernel<true>, dim3(pda::divup(nblocks, 8) * 8), dim3(512), 2 * pda::WSP_TILE_U4 * 16, st,
+                               x, grad_out, part_w, grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks, x_mi, x_g, x_b);
+        else
+            hipLaunchKernelGGL(pda::wgrad_split_kernel<false>, dim3(pda::divup(nblocks, 8) * 8), dim3(512), 2 * pda::WSP_TILE_U4 * 16, st,
+                               x, grad_out, part_w, grad_bias ? part_b : (float*)nullptr, tokens, M, N, tm, tn, S, KS, nblocks, x_mi, x_g, x_b);
         const int64_t nm = (int64_t)N * M;
         hipLaunchKernelGGL(pda::wgrad_reduce_kernel, dim3((unsigned)pda::divup64(nm, 64)), dim3(1024), 0, st, part_w, part_b,
                            grad_weight, grad_bias, S, nm, N);

@@ -422,6 +422,71 @@ def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_f
     return 1
 
 
+def linear_wgrad_bn(x, grad_out, grad_weight, tokens, in_features, out_features, x_mean_invstd, x_gamma, x_beta):
+    """grad_weight (out, in) = grad_out^T relu(bn(x)) with the BatchNorm + ReLU of the PRE-BatchNorm tensor x formed in the
+    operand load (csrc/wgrad.hip, split form only: PdaError otherwise)."""
+    _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
+    _numel_ok(grad_weight, in_features * out_features, "grad_weight"); _numel_ok(x_mean_invstd, 2 * in_features, "x_mean_invstd")
+    _numel_ok(x_gamma, in_features, "x_gamma"); _numel_ok(x_beta, in_features, "x_beta")
+    key = (tokens, in_features, out_features)
+    nbytes = _WGRAD_SCRATCH_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WGRAD_SCRATCH_BYTES[key] = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
+    _call("pda_linear_wgrad_bn", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32), None,
+          _chk(scratch, "scratch", torch.uint8), tokens, in_features, out_features, _chk(x_mean_invstd, "x_mean_invstd", F32),
+          _chk(x_gamma, "x_gamma", F32), _chk(x_beta, "x_beta", F32))
+    return 1
+
+
+def gemm_split_bn_tiles(tokens):
+    return (int(tokens) + 255) // 256          # == pda_gemm_split_bn_tiles (tests/test_capi_symbols.py)
+
+
+def gemm_split_bn(x, wf, y, tokens, k, n_out, in_bn=None, stats_mode=0, partial=None):
+    """y = X' W^T on the 256 x 256 tile split-bf16 kernel; X' = relu(bn(x)) when in_bn = (mean_invstd, gamma, beta) of the input
+    channels; stats_mode 1: `partial` [tiles][2][n_out] (float64) receives the per-column sums of y (include/pda_train.h)."""
+    _numel_ok(x, tokens * k, "x"); _numel_ok(y, tokens * n_out, "y")
+    _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")
+    ib = (None, None, None)
+    if in_bn is not None:
+        _numel_ok(in_bn[0], 2 * k, "in_mean_invstd"); _numel_ok(in_bn[1], k, "in_gamma"); _numel_ok(in_bn[2], k, "in_beta")
+        ib = tuple(_chk(t, "in_bn", F32) for t in in_bn)
+    if stats_mode:
+        _numel_ok(partial, gemm_split_bn_tiles(tokens) * 2 * n_out, "partial")
+    _call("pda_gemm_split_bn", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), _chk(y, "y", F32), tokens, k, n_out, ib[0], ib[1], ib[2],
+          int(stats_mode), None if partial is None else _chk(partial, "partial", torch.float64))
+    return 1
+
+
+def bn_stats_fwd(x, running_mean, running_var, mean_invstd, scratch, rows, c, eps, momentum):
+    """The statistics pass of bn_relu_fwd alone (mean_invstd (2, C); running statistics updated)."""
+    _numel_ok(x, rows * c, "x"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
+    rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
+    rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _buffers_written(rm)
+    _call("pda_bn_stats_fwd", x, _chk(x, "x", F32), rm, rv, _chk(mean_invstd, "mean_invstd", F32), _chk(scratch, "scratch", torch.uint8),
+          rows, c, float(eps), float(momentum))
+    return 1
+
+
+def bn_finalize_fwd(partial, nblocks, c, count, eps, momentum, mean_invstd, running_mean, running_var):
+    _numel_ok(partial, nblocks * 2 * c, "partial"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
+    rm = None if running_mean is None else _chk(running_mean, "running_mean", F32)
+    rv = None if running_var is None else _chk(running_var, "running_var", F32)
+    _buffers_written(rm)
+    _call("pda_bn_finalize_fwd", partial, _chk(partial, "partial", torch.float64), nblocks, c, count, float(eps), float(momentum),
+          _chk(mean_invstd, "mean_invstd", F32), rm, rv)
+    return 1
+
+
+def bn_relu_max_pool_apply(x, gamma, beta, mean_invstd, out, arg, groups, ns, c):
+    _numel_ok(x, groups * ns * c, "x"); _numel_ok(out, groups * c, "out"); _numel_ok(arg, groups * c, "arg"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")
+    _call("pda_bn_relu_max_pool_apply", x, _chk(x, "x", F32), _chk(gamma, "gamma", F32), _chk(beta, "beta", F32),
+          _chk(mean_invstd, "mean_invstd", F32), _chk(out, "out", F32), _chk(arg, "arg", torch.uint8), groups, ns, c)
+    return 1
+
+
 def colsum_bf16(g, out, rows, cols):
     """MI355X extension: out (cols) fp32 = column sums of the bf16 matrix g (rows, cols): the bias gradient in dense-bf16
     mode (csrc/wgrad.hip; fixed summation order)."""

@@ -429,6 +429,12 @@ class PointnetSAModuleMSG_WithSampling(_SAModuleBase):
                         g = pointnet2_utils.sa_small_chain_train(xyz, new_xyz, feats_pm, idxs[i], self.mlps[i])
                         new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
                         continue
+                    if (self.training and torch.is_grad_enabled()
+                            and pointnet2_utils.SaWideChainTrain.supported(xyz, new_xyz, feats_pm, idxs[i], self.mlps[i])):
+                        # wide chains (layer 5): BatchNorm statistics in the GEMM epilogues, normalisation in the operand loads
+                        g = pointnet2_utils.sa_wide_chain_train(xyz, new_xyz, feats_pm, idxs[i], self.mlps[i])
+                        new_features_list.append(g.transpose(1, 2))             # (B, mlp[-1], M) view
+                        continue
                     conv1 = self.mlps[i][0]
                     w1 = conv1.weight.flatten(1)
                     if (torch.is_grad_enabled() and isinstance(conv1, nn.Conv2d) and conv1.bias is None

@@ -1136,6 +1136,7 @@ def sa_wide_scale_infer(xyz, new_xyz, feats_pm, idx, folded):
 # SA_SMALL_TRAIN: group -> [conv1x1 -> BN(batch statistics) -> ReLU] x 3 -> max of a scale whose widths are <= 64 runs as
 # four forward and four backward passes over the neighbour lists; no (B, M, ns, C) tensor exists in the forward pass.
 SA_SMALL_TRAIN = True
+FUSED_WIDE_CHAIN_OK = True      # (tests switch the wide chain off to compare it with the unfused path)
 
 
 class SaSmallChainTrain(Function):
@@ -1212,6 +1213,139 @@ def sa_small_chain_train(xyz, new_xyz, feats_pm, idx, mlp):
     return SaSmallChainTrain.apply(xyz, new_xyz, feats_pm, idx, convs[0].weight.flatten(1), convs[1].weight.flatten(1),
                                    convs[2].weight.flatten(1), bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias,
                                    bns[2].weight, bns[2].bias, bns)
+
+
+# ---- the WIDE vanilla SA scale (layer 5) in training form with the BatchNorm passes folded into the contractions ------------
+# SA_WIDE_CHAIN: group -> [conv1x1 -> BN(batch statistics) -> ReLU] x 3 -> max of a scale whose first layer is the per-point
+# projection of SaPointLinear and whose widths are multiples of 256.  Between the three contractions only the PRE-BatchNorm
+# tensors z1, z2, z3 reach HBM: a layer's statistics come out of the epilogue of the GEMM that produces it and its normalised
+# activation is formed in the operand load of the GEMM (and of the weight gradient) that consumes it
+# (pda_gemm_split_bn, pda_linear_wgrad_bn): per mid layer the forward statistics pass, the normalise pass and the activation's
+# write + two reads go.  (The reduction pass of the BatchNorm BACKWARD in the epilogue of the input-gradient GEMM was built and
+# measured too: reading z tile by tile behind a 256 x 256 tile's stores costs more than the standalone pass, +0.23 ms on
+# 131072 x 512 x 512 against 0.10 ms, and was removed.)
+SA_WIDE_CHAIN = os.environ.get("PDA_SA_WIDE_CHAIN", "1") != "0"
+SA_WIDE_CHAIN_MIN_TOKENS = int(os.environ.get("PDA_SA_WIDE_CHAIN_MIN_TOKENS", "16384"))   # (at 32768 tokens the 256 x 256 tiles take 50 us against lin_split's 35, the passes saved are worth more)
+
+
+class SaWideChainTrain(Function):
+    """One scale of PointnetSAModuleMSG_WithSampling (pointnet2_modules.py:1657-1670): out (B, M, c3) = max over nsample of the
+    three-layer MLP of [xyz[idx] - new_xyz | feats[idx]], training-mode BatchNorm.  Same results as SaPointLinear +
+    BatchNormReLU + the split GEMMs + BatchNormReLUMaxPool up to the order of the statistics' sums."""
+
+    @staticmethod
+    def supported(xyz, new_xyz, feats_pm, idx, mlp):
+        layers = list(mlp)
+        if not (SA_WIDE_CHAIN and FUSED_WIDE_CHAIN_OK and len(layers) == 9 and feats_pm is not None and idx is not None):
+            return False
+        convs, bns = [layers[0], layers[3], layers[6]], [layers[1], layers[4], layers[7]]
+        if not (all(isinstance(c, nn.Conv2d) and c.bias is None and c.weight.dtype == torch.float32 for c in convs)
+                and all(isinstance(b, nn.BatchNorm2d) and b.affine and b.training and b.momentum is not None for b in bns)
+                and all(isinstance(layers[k], nn.ReLU) for k in (2, 5, 8))):
+            return False
+        w1 = convs[0].weight.flatten(1)
+        if not SaPointLinear.supported(xyz, feats_pm, w1):
+            return False
+        c1, c2, c3 = (c.weight.shape[0] for c in convs)
+        T = idx.shape[0] * idx.shape[1] * idx.shape[2]
+        if not (c1 % 256 == 0 and c2 % 256 == 0 and c3 % 256 == 0 and max(c1, c2, c3) <= 1024 and 1 <= idx.shape[2] <= 255
+                and T >= SA_WIDE_CHAIN_MIN_TOKENS and not DENSE_BF16 and not torch.is_autocast_enabled()):
+            return False
+        lib = _lib.load()
+        return int(lib.pda_linear_wgrad_form(T, c1, c2)) == 2 and int(lib.pda_linear_wgrad_form(T, c2, c3)) == 2
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats_pm, idx, w1, w2, w3, g1, b1, g2, b2, g3, b3, bns):
+        B, N, _ = xyz.shape
+        M, ns = idx.shape[1], idx.shape[2]
+        C, c1, c2, c3 = feats_pm.shape[-1], w1.shape[0], w2.shape[0], w3.shape[0]
+        T = B * M * ns
+        dev = xyz.device
+        xyz, new_xyz, feats_pm, idx = xyz.contiguous(), new_xyz.contiguous(), feats_pm.contiguous(), idx.contiguous()
+        gs = [t.detach().contiguous() for t in (g1, g2, g3)]
+        bs = [t.detach().contiguous() for t in (b1, b2, b3)]
+        stats = [(bn.running_mean, bn.running_var) if bn.track_running_stats else (None, None) for bn in bns]
+        w1d = w1.detach().contiguous()
+        # layer 1: per-point projection + row gather (SaPointLinear), then its statistics
+        rows = _gemm_nt(feats_pm.view(B * N, C), w1d[:, 3:].contiguous())
+        z1 = torch.empty((T, c1), dtype=torch.float32, device=dev)
+        pointnet2.sa_point_gather(rows, xyz, new_xyz, idx, w1d, z1, B, N, M, ns, c1)
+        mi1 = torch.empty((2 * c1,), dtype=torch.float32, device=dev)
+        scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c1),), dtype=torch.uint8, device=dev)
+        pointnet2.bn_stats_fwd(z1, stats[0][0], stats[0][1], mi1, scratch, T, c1, bns[0].eps, bns[0].momentum)
+        # layers 2 and 3: z = relu(bn(z_prev)) W^T with the statistics of z in the epilogue
+        tiles = pointnet2.gemm_split_bn_tiles(T)
+
+        def layer(z_in, mi_in, k, w, n_out, bn, st, gi, bi):
+            z = torch.empty((T, n_out), dtype=torch.float32, device=dev)
+            part = torch.empty((tiles * 2 * n_out,), dtype=torch.float64, device=dev)
+            wf = _split_planes(w)
+            _sa_timed(2.0 * T * k * n_out, lambda: pointnet2.gemm_split_bn(z_in, wf, z, T, k, n_out, in_bn=(mi_in, gi, bi), stats_mode=1,
+                                                                           partial=part), "bf16x6")
+            mi = torch.empty((2 * n_out,), dtype=torch.float32, device=dev)
+            pointnet2.bn_finalize_fwd(part, tiles, n_out, T, bn.eps, bn.momentum, mi, st[0], st[1])
+            return z, mi
+        z2, mi2 = layer(z1, mi1, c1, w2, c2, bns[1], stats[1], gs[0], bs[0])
+        z3, mi3 = layer(z2, mi2, c2, w3, c3, bns[2], stats[2], gs[1], bs[1])
+        out = torch.empty((B, M, c3), dtype=torch.float32, device=dev)
+        arg = torch.empty((B, M, c3), dtype=torch.uint8, device=dev)
+        pointnet2.bn_relu_max_pool_apply(z3, gs[2], bs[2], mi3, out, arg, B * M, ns, c3)
+        ctx.save_for_backward(xyz, new_xyz, feats_pm, idx, w1, w2, w3, g1, b1, g2, b2, g3, b3, z1, z2, z3, mi1, mi2, mi3, arg)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        xyz, new_xyz, feats_pm, idx, w1, w2, w3, g1, b1, g2, b2, g3, b3, z1, z2, z3, mi1, mi2, mi3, arg = ctx.saved_tensors
+        B, M, ns = idx.shape
+        N, C = xyz.shape[1], feats_pm.shape[-1]
+        c1, c2, c3 = w1.shape[0], w2.shape[0], w3.shape[0]
+        T = B * M * ns
+        dev = xyz.device
+        tiles = pointnet2.gemm_split_bn_tiles(T)
+        with torch.no_grad():
+            g1c, b1c, g2c, b2c, g3c, b3c = (t.contiguous() for t in (g1, b1, g2, b2, g3, b3))
+            # BatchNorm 3 + max-pool: the gradient reaches one row per (group, channel)
+            gz3 = torch.empty((T, c3), dtype=torch.float32, device=dev)
+            dg3, db3 = torch.empty_like(g3c), torch.empty_like(b3c)
+            scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(c3),), dtype=torch.uint8, device=dev)
+            pointnet2.bn_relu_max_pool_bwd(z3, grad_out.contiguous().float(), arg, g3c, b3c, mi3, gz3, dg3, db3, scratch, B * M, ns, c3)
+
+            def layer(gz, w, z_in, mi_in, gi, bi, k_in, n_out):
+                """gz (T, n_out) = gradient at this layer's output z; returns (dW, gradient at z_in, dgamma_in, dbeta_in)."""
+                dw = torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
+                pointnet2.linear_wgrad_bn(z_in, gz, dw, T, k_in, n_out, mi_in, gi, bi)
+                ga = torch.empty((T, k_in), dtype=torch.float32, device=dev)
+                _lin_cols(gz, w, ga, T, n_out, k_in, True)                                    # ga = gz W (timed as a bf16x6 launch)
+                dg, db = torch.empty_like(gi), torch.empty_like(bi)
+                scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(k_in),), dtype=torch.uint8, device=dev)
+                pointnet2.bn_relu_bwd(z_in, ga, gi, bi, mi_in, ga, dg, db, scratch, T, k_in)   # in place: a thread reads what it writes
+                return dw, ga, dg, db
+            dw3, gz2, dg2, db2 = layer(gz3, w3, z2, mi2, g2c, b2c, c2, c3)
+            del gz3
+            dw2, gz1, dg1, db1 = layer(gz2, w2, z1, mi1, g1c, b1c, c1, c2)
+            del gz2
+            # layer 1 (SaPointLinear.backward): coordinate columns and centres, then the feature columns through the points
+            w1c = w1.contiguous()
+            dw1 = torch.empty_like(w1c)
+            g_new = torch.empty_like(new_xyz) if ctx.needs_input_grad[1] else None
+            pointnet2.sa_xyz_grad(gz1, xyz, new_xyz, idx, w1c, dw1, g_new, B, N, M, ns, c1)
+            g_pts = torch.zeros((B, N, c1), dtype=torch.float32, device=dev)
+            pointnet2.group_rows_grad(B, N, c1, M * ns, gz1, idx, g_pts)
+            g_pts = g_pts.view(B * N, c1)
+            dw1[:, 3:] = _wgrad(feats_pm.view(B * N, C), g_pts, torch.empty((c1, C), dtype=torch.float32, device=dev), False)[0]
+            g_feats = _gemm_nn(g_pts, w1c[:, 3:].contiguous()).view(B, N, C) if ctx.needs_input_grad[2] else None
+        return None, g_new, g_feats, None, dw1, dw2, dw3, dg1, db1, dg2, db2, dg3, db3, None
+
+
+def sa_wide_chain_train(xyz, new_xyz, feats_pm, idx, mlp):
+    """The scale's [conv -> BN -> ReLU] x 3 nn.Sequential `mlp` applied through SaWideChainTrain: (B, M, c3)."""
+    layers = list(mlp)
+    convs, bns = [layers[0], layers[3], layers[6]], [layers[1], layers[4], layers[7]]
+    for bn in bns:
+        bump_bn_counter(bn)
+    return SaWideChainTrain.apply(xyz, new_xyz, feats_pm, idx, convs[0].weight.flatten(1), convs[1].weight.flatten(1),
+                                  convs[2].weight.flatten(1), bns[0].weight, bns[0].bias, bns[1].weight, bns[1].bias,
+                                  bns[2].weight, bns[2].bias, bns)
 
 
 # ---- unique-token ("ragged") execution of a PDA scale (csrc/ragged.hip) --------------------------------------------

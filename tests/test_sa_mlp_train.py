@@ -147,3 +147,82 @@ def test_sa_point_linear_equals_gather_linear():
     assert (za - zb).abs().max().item() <= 2e-5 * zb.abs().max().item()
     for a, b, name in ((ca, cb, "centres"), (fa, fb, "features"), (wa, wb, "weight")):
         assert (a - b).abs().max().item() <= 3e-4 * b.abs().max().item(), name
+
+
+def test_sa_wide_chain_equals_unfused_path():
+    """SaWideChainTrain (BatchNorm statistics in the GEMM epilogues, normalisation + ReLU in the operand loads of the next GEMM
+    and of the weight gradient, the BatchNorm backward's reduction in the input-gradient GEMM's epilogue) against the same
+    scale op by op (SaPointLinear, bn_relu passes, split GEMMs, fused pool): outputs, input gradients, every parameter
+    gradient, running statistics -- at ONCE layer 5's token counts (65536 and 131072)."""
+    from pdanet_amd import pointnet2_utils as pu, synth
+    from pdanet_amd.pointnet2_modules import PointnetSAModuleMSG_WithSampling
+    B, N, M = 2, 2048, 1024
+    xyz = torch.from_numpy(synth.batch_xyz(B, N, config_id=6)).cuda()
+    feats0 = torch.randn(B, 256, N, device="cuda", generator=torch.Generator("cuda").manual_seed(11))
+    res = {}
+    used = {}
+    try:
+        for flag in (True, False):
+            pu.FUSED_WIDE_CHAIN_OK = flag
+            used[flag] = pu.SA_MFMA_EVENTS = []
+            layer = PointnetSAModuleMSG_WithSampling(
+                npoint_list=[M], sample_range_list=[-1], sample_type_list=["D-FPS"], radii=[8.4, 12.8], nsamples=[32, 64],
+                mlps=[[256, 256, 256, 512], [256, 256, 512, 512]], use_xyz=True, dilated_group=False, aggregation_mlp=[512],
+                confidence_mlp=None, num_class=5)
+            layer = fill_deterministic(layer).cuda().train()
+            feats = feats0.clone().requires_grad_(True)
+            ctr = (xyz[:, :M] + 0.05).contiguous().requires_grad_(True)
+            for _ in range(2):                     # two iterations: the running statistics move twice
+                _, nf, _, _ = layer(xyz, feats, None, ctr_xyz=ctr)
+                nf.pow(2).mean().backward()
+            res[flag] = (nf.detach(), feats.grad.clone(), ctr.grad.clone(),
+                         {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None},
+                         {k: v.clone() for k, v in layer.state_dict().items() if "running" in k or "num_batches" in k})
+    finally:
+        pu.FUSED_WIDE_CHAIN_OK, pu.SA_MFMA_EVENTS = True, None
+    torch.cuda.synchronize()
+    assert len(used[True]) == 2 * 2 * 4, len(used[True])       # per scale and iteration: 2 forward + 2 input-gradient launches
+    a, b = res[True], res[False]
+    assert (a[0] - b[0]).abs().max().item() <= 2e-5 * max(1.0, b[0].abs().max().item())
+    for i in (1, 2):
+        assert (a[i] - b[i]).abs().max().item() <= 2e-4 * b[i].abs().max().item() + 1e-9
+    gmax = max(float(v.abs().max()) for v in b[3].values())
+    assert set(a[3]) == set(b[3])
+    for k in b[3]:
+        assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-3 * float(b[3][k].abs().max()) + 1e-4 * gmax, k
+    for k in b[4]:
+        assert torch.allclose(a[4][k].float(), b[4][k].float(), rtol=1e-5, atol=1e-6), k
+
+
+def test_gemm_split_bn_pieces_against_fp64():
+    """pda_gemm_split_bn on its own: the input BatchNorm + ReLU in the operand load and the output statistics of the epilogue
+    against float64; pda_linear_wgrad_bn against float64."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    T, K, Nn = 33001, 256, 512                     # a ragged last tile
+    g = torch.Generator("cuda").manual_seed(5)
+    x = torch.randn(T, K, device="cuda", generator=g) * 1.5 + 0.2
+    w = torch.randn(Nn, K, device="cuda", generator=g) * 0.05
+    gam, bet = torch.rand(K, device="cuda", generator=g) + 0.5, torch.randn(K, device="cuda", generator=g) * 0.3
+    mean, var = x.double().mean(0), x.double().var(0, unbiased=False)
+    mi = torch.cat([mean, 1.0 / torch.sqrt(var + 1e-5)]).float().contiguous()
+    a64 = torch.relu((x.double() - mi[:K].double()) * mi[K:].double() * gam.double() + bet.double())
+    wf = ext.linear_split_pack(w, Nn, K)
+    tiles = ext.gemm_split_bn_tiles(T)
+    y = torch.full((T, Nn), float("nan"), device="cuda")
+    part = torch.full((tiles * 2 * Nn,), float("nan"), dtype=torch.float64, device="cuda")
+    ext.gemm_split_bn(x, wf, y, T, K, Nn, in_bn=(mi, gam, bet), stats_mode=1, partial=part)
+    y64 = a64 @ w.double().t()
+    scale = a64.abs() @ w.double().abs().t() + 1e-30
+    assert ((y.double() - y64).abs() / scale).max().item() < 3e-6
+    p = part.view(tiles, 2, Nn).sum(0)
+    assert torch.allclose(p[0], y.double().sum(0), rtol=1e-12, atol=1e-9) and torch.allclose(p[1], (y.double() ** 2).sum(0), rtol=1e-12)
+    # weight gradient against relu(bn(x)) formed in the operand load
+    T2 = 65536
+    x2 = torch.randn(T2, K, device="cuda", generator=g) + 0.1
+    g2 = torch.randn(T2, Nn, device="cuda", generator=g)
+    mi2 = torch.cat([x2.double().mean(0), 1.0 / torch.sqrt(x2.double().var(0, unbiased=False) + 1e-5)]).float().contiguous()
+    dw = torch.empty(Nn, K, device="cuda")
+    ext.linear_wgrad_bn(x2, g2, dw, T2, K, Nn, mi2, gam, bet)
+    a2 = torch.relu((x2 - mi2[:K]) * mi2[K:] * gam + bet).double()
+    want = g2.double().t() @ a2
+    assert ((dw.double() - want).abs() / (g2.double().abs().t() @ a2.abs() + 1e-30)).max().item() < 3e-6
