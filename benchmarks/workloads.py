@@ -127,6 +127,8 @@ class KernelTimers:
                                      lambda b, n, m, radii, ns, *r: (b, n, m, tuple(radii), tuple(ns), "cell list"))
         ext.linear_wgrad = timed(unwrap(ext.linear_wgrad), self.wgrad_events,
                                  lambda x, g, gw, gb, tokens, n_in, n_out: (tokens, n_in, n_out))
+        ext.linear_wgrad_bn = timed(unwrap(ext.linear_wgrad_bn), self.wgrad_events,      # the same kernel, BatchNorm in its operand load
+                                    lambda x, g, gw, tokens, n_in, n_out, *r: (tokens, n_in, n_out))
 
     @staticmethod
     def _mean_s(events):

@@ -1225,7 +1225,7 @@ def sa_small_chain_train(xyz, new_xyz, feats_pm, idx, mlp):
 # measured too: reading z tile by tile behind a 256 x 256 tile's stores costs more than the standalone pass, +0.23 ms on
 # 131072 x 512 x 512 against 0.10 ms, and was removed.)
 SA_WIDE_CHAIN = os.environ.get("PDA_SA_WIDE_CHAIN", "1") != "0"
-SA_WIDE_CHAIN_MIN_TOKENS = int(os.environ.get("PDA_SA_WIDE_CHAIN_MIN_TOKENS", "16384"))   # (at 32768 tokens the 256 x 256 tiles take 50 us against lin_split's 35, the passes saved are worth more)
+SA_WIDE_CHAIN_MIN_TOKENS = int(os.environ.get("PDA_SA_WIDE_CHAIN_MIN_TOKENS", "32768"))   # (at 32768 tokens the 256 x 256 tiles take 50 us against lin_split's 35 and the passes saved are still worth more; at 16384 they are not)
 
 
 class SaWideChainTrain(Function):
