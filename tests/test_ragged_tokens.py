@@ -133,6 +133,35 @@ def test_pda_layer_ragged_equals_dense(mode):
         assert float((a[3][k] - b[3][k]).abs().max()) <= 1e-2 * s + 1e-3 * gmax, k
 
 
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_count_read_overlap_changes_no_result(mode):
+    """pointnet2_modules.PLAN_OVERLAP (the host waits for the token counts through an event, after enqueuing the work that needs
+    no count, and runs the larger scale first) against the blocking read in the original scale order: the same kernels on the
+    same operands -- forward outputs bit for bit (gradients sum float atomics, so those are compared to 1e-5)."""
+    from pdanet_amd import pointnet2_modules as pm, synth
+    xyz = torch.from_numpy(synth.batch_xyz(2, 4096, config_id=2)).cuda()
+    feats0 = torch.randn(2, 64, 4096, device="cuda", generator=torch.Generator("cuda").manual_seed(6))
+    res = {}
+    try:
+        for flag in (True, False):
+            pm.PLAN_OVERLAP = flag
+            layer = _pda_layer().train(mode == "train")
+            feats = feats0.clone().requires_grad_(mode == "train")
+            with torch.set_grad_enabled(mode == "train"):
+                nx, nf, cf, _ = layer(xyz, feats, None)
+            g = None
+            if mode == "train":
+                (nf.pow(2).mean() + cf.pow(2).mean()).backward()
+                g = feats.grad.clone()
+            res[flag] = (nx, nf.detach(), cf.detach(), g)
+    finally:
+        pm.PLAN_OVERLAP = True
+    a, b = res[True], res[False]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+    if mode == "train":
+        assert (a[3] - b[3]).abs().max().item() <= 1e-5 * b[3].abs().max().item()
+
+
 def test_dense_scale_is_left_alone_above_the_fraction_threshold():
     from pdanet_amd import pointnet2_utils as pu
     rng = np.random.default_rng(3)
