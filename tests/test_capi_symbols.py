@@ -61,6 +61,13 @@ def test_argument_validation_without_gpu(lib):
     assert st == 1
     st = lib.pda_group_points(None, None, None, 1, 1, 1, -1, 1, None)
     assert st == 1
+    # the BatchNorm-folded contraction: sizes, pointer pairing and the statistics mode are checked before anything is launched
+    assert lib.pda_gemm_split_bn_tiles(0) == 0 and lib.pda_gemm_split_bn_tiles(1) == 1 and lib.pda_gemm_split_bn_tiles(131072) == 512
+    assert lib.pda_gemm_split_bn_tiles(131073) == 513
+    assert lib.pda_gemm_split_bn(None, None, None, 0, 256, 256, None, None, None, 0, None, None) == 1 and b"bad size" in lib.pda_last_error()
+    assert lib.pda_gemm_split_bn(None, None, None, 4096, 256, 256, None, None, None, 0, None, None) == 1 and b"null" in lib.pda_last_error()
+    assert lib.pda_linear_wgrad_bn(None, None, None, None, None, 65536, 256, 256, None, None, None, None) == 1
+    assert lib.pda_bn_finalize_fwd(None, 0, 64, 100, ctypes.c_float(1e-5), ctypes.c_float(0.1), None, None, None, None) == 1
     # empty problems are PDA_OK and touch nothing
     assert lib.pda_ball_query(None, None, None, 0, 8, 8, ctypes.c_float(1.0), 4, None) == 0
     assert lib.pda_furthest_point_sampling(None, None, None, 2, 8, 0, None) == 0
