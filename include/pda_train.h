@@ -120,6 +120,11 @@ int64_t pda_gemm_split_bn_tiles(int64_t tokens);
 int pda_gemm_split_bn(const float *x, const void *wf, float *y, int64_t tokens, int k, int n_out,
                       const float *in_mean_invstd, const float *in_gamma, const float *in_beta, int stats_mode,
                       double *partial, pda_stream_t stream);
+/* Inference: out (tokens / ns, n_out) = max over every group of ns consecutive token rows of relu?(x W^T + bias) -- the last layer
+ * of an SA scale with the max over nsample in the epilogue; the (tokens, n_out) tensor is never written.  ns in {16, 32, 64},
+ * tokens a multiple of ns, K a multiple of 32.  Same arithmetic as pda_gemm_split followed by the max. */
+int pda_gemm_split_maxpool(const float *x, const void *wf, const float *bias, float *out, int64_t tokens, int k, int n_out,
+                           int ns, int relu, pda_stream_t stream);
 /* The passes of pda_bn_relu_fwd / pda_bn_relu_max_pool_fwd one at a time.  pda_bn_stats_fwd: statistics of x only
  * (mean_invstd (2, C), running statistics updated); scratch: pda_bn_relu_scratch_bytes(c).  pda_bn_finalize_fwd: the same
  * from `nblocks` rows of per-block sums [nblocks][2][C] (count = the number of rows they cover).

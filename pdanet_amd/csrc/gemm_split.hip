@@ -246,7 +246,8 @@ struct GemmSplitParams {
     const float* in_mi;     // PRO: (2, K) mean | invstd of the INPUT channels; X is read as relu((x - mean) * invstd * gamma + beta)
     const float* in_g;      //      (K) gamma
     const float* in_b;      //      (K) beta
-    double* partial;        // EPI: [token tile][2][n_out] per-column sum / sum of squares of this launch's output
+    double* partial;        // EPI 1: [token tile][2][n_out] per-column sum / sum of squares of this launch's output
+    int pool_ns;            // EPI 2: y is (tokens / pool_ns, n_out), the max over each group of pool_ns consecutive token rows
 };
 
 constexpr int GT_XCHUNKS = 128 * 4;                  // uint4 per X tile (128 rows x 64 bytes)
@@ -390,7 +391,8 @@ typedef uint32_t gp_u32x4 __attribute__((ext_vector_type(4)));
 //   split, so relu(bn(x)) never exists in HBM.  The four per-channel constants sit in LDS behind the plane buffers.
 // EPI = 1: besides storing Y, the workgroup writes the per-column sum and sum of squares of its 256 token rows (double,
 //   fixed order: 32 rows per lane, the two half-waves, then the four token-waves) -- the statistics pass of the BatchNorm
-//   that follows, without reading Y again.  (The reduction pass of the BatchNorm BACKWARD in the epilogue of the
+//   that follows, without reading Y again.  EPI = 2 (inference): only the max over every group of pool_ns consecutive token
+//   rows leaves the kernel (the max-pool over nsample behind the last layer of an SA scale).  (The reduction pass of the BatchNorm BACKWARD in the epilogue of the
 //   input-gradient GEMM, z read tile by tile next to the stores, was measured and removed: 131072 x 512 -> 512 went from
 //   0.36 to 0.60 ms, the standalone pass costs 0.10.)
 template <int PRO, int EPI>
@@ -552,6 +554,47 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
     for (int e = 0; e < 12; ++e)                   // output block 3 of the last step
         acc[e & 1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A0[e & 1][PA[e >> 1]], Bf[1][PB[e >> 1]], acc[e & 1][3], 0, 0, 0);
     // rows of a 32 x 32 tile: token (i & 3) + 8 (i >> 2) + 4 h; column: output (2 ncb + wo) * 128 + ot * 32 + r
+    if constexpr (EPI == 2) {
+        // Pooled output: out[group][col] = max over the group's p.pool_ns consecutive token rows of relu?(acc + bias); Y itself is
+        // never written.  pool_ns in {16, 32, 64} divides the 64 tokens of a wave, so a group lives in one wave: eight / sixteen /
+        // thirty-two registers of a lane (rows (i & 3) + 8 (i >> 2) + 4 h cover 16 consecutive rows for i >> 3 fixed), then the
+        // other half-wave.
+        const int ns = p.pool_ns;
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) {
+            const int col = (2 * ncb + wo) * 128 + ot * 32 + r;
+            const float bias = (p.bias && col < p.n_out) ? p.bias[col] : 0.f;
+            float g16[4];                           // the four groups of 16 rows of this wave's 64 tokens
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    float m = -__builtin_inff();
+#pragma unroll
+                    for (int i = 8 * half; i < 8 * half + 8; ++i) {
+                        float v = acc[tt][ot][i] + bias;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        m = fmaxf(m, v);
+                    }
+                    g16[2 * tt + half] = fmaxf(m, __shfl_xor(m, 32));
+                }
+            if (h == 0 && col < p.n_out) {
+                const int64_t t0 = tok0 + wt * 64;                  // first token of the wave
+                if (ns == 16) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (t0 + 16 * q < p.tokens) p.y[((t0 + 16 * q) >> 4) * p.n_out + col] = g16[q];
+                } else if (ns == 32) {
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (t0 + 32 * q < p.tokens) p.y[((t0 + 32 * q) >> 5) * p.n_out + col] = fmaxf(g16[2 * q], g16[2 * q + 1]);
+                } else if (t0 < p.tokens) {
+                    p.y[(t0 >> 6) * p.n_out + col] = fmaxf(fmaxf(g16[0], g16[1]), fmaxf(g16[2], g16[3]));
+                }
+            }
+        }
+        return;
+    }
     double cs1[4], cs2[4];                          // EPI: this lane's column sums (one column per output block)
 #pragma unroll
     for (int ot = 0; ot < 4; ++ot) {
@@ -579,7 +622,7 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
             }
         }
     }
-    if constexpr (EPI != 0) {
+    if constexpr (EPI == 1) {
         // lanes r and r + 32 hold the same columns; the four token-waves of an output-wave too: LDS [wt][column 0..255][2]
         double* red = reinterpret_cast<double*>(gp_planes);
         __syncthreads();                            // every wave is done with the plane buffers
@@ -740,4 +783,28 @@ PDA_API int pda_gemm_split_bn(const float* x, const void* wf, float* y, int64_t 
     PDA_REQUIRE(hipLaunchKernel(fn, dim3((unsigned)wide_blocks), dim3(512), args, lds, (hipStream_t)stream) == hipSuccess,
                 "pda_gemm_split_bn: launch failed");
     return pda::check_launch("pda_gemm_split_bn");
+}
+
+// out (tokens / ns, n_out) = max over each group of ns consecutive token rows of relu?(x W^T + bias): the last layer of an SA
+// scale in inference with the max over nsample in the epilogue (ns in {16, 32, 64}; tokens a multiple of ns).
+PDA_API int pda_gemm_split_maxpool(const float* x, const void* wf, const float* bias, float* out, int64_t tokens, int k, int n_out, int ns,
+                                   int relu, pda_stream_t stream) {
+    PDA_REQUIRE(tokens >= 0 && k > 0 && n_out > 0, "pda_gemm_split_maxpool: bad size");
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(x && wf && out && (((uintptr_t)x | (uintptr_t)wf) & 15) == 0, "pda_gemm_split_maxpool: null or misaligned pointer");
+    if (k % 32 != 0 || (ns != 16 && ns != 32 && ns != 64) || tokens % ns != 0) {
+        pda::set_error("pda_gemm_split_maxpool: K=%d (a multiple of 32), ns=%d (16, 32 or 64), tokens=%lld (a multiple of ns)", k, ns, (long long)tokens);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::GemmSplitParams p{};
+    p.x = x; p.wf = (const uint4*)wf; p.bias = bias; p.y = out; p.tokens = tokens; p.k = k; p.n_out = n_out;
+    p.chunks = pda::divup(n_out, 128); p.ksteps = k / 16; p.relu = relu; p.pool_ns = ns;
+    const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
+    PDA_REQUIRE(wide_blocks < (1ll << 31), "pda_gemm_split_maxpool: too many tiles");
+    static pda::PerDevice<bool> lds_ok;
+    const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel<0, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               2 * pda::GW_TILE_U4 * 16) == hipSuccess; });
+    PDA_REQUIRE(ok, "pda_gemm_split_maxpool: dynamic LDS refused");
+    hipLaunchKernelGGL((pda::gemm_split_wide_kernel<0, 2>), dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16, (hipStream_t)stream, p);
+    return pda::check_launch("pda_gemm_split_maxpool");
 }

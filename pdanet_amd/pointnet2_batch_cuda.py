@@ -459,6 +459,17 @@ def gemm_split_bn(x, wf, y, tokens, k, n_out, in_bn=None, stats_mode=0, partial=
     return 1
 
 
+def gemm_split_maxpool(x, wf, bias, out, tokens, k, n_out, ns, relu=True):
+    """out (tokens / ns, n_out) = max over each group of ns consecutive rows of relu?(x W^T + bias) (csrc/gemm_split.hip)."""
+    _numel_ok(x, tokens * k, "x"); _numel_ok(out, (tokens // ns) * n_out, "out")
+    _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")
+    if bias is not None:
+        _numel_ok(bias, n_out, "bias")
+    _call("pda_gemm_split_maxpool", x, _chk(x, "x", F32), _chk(wf, "wf", torch.uint8), None if bias is None else _chk(bias, "bias", F32),
+          _chk(out, "out", F32), tokens, k, n_out, ns, 1 if relu else 0)
+    return 1
+
+
 def bn_stats_fwd(x, running_mean, running_var, mean_invstd, scratch, rows, c, eps, momentum):
     """The statistics pass of bn_relu_fwd alone (mean_invstd (2, C); running statistics updated)."""
     _numel_ok(x, rows * c, "x"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")

@@ -1124,6 +1124,12 @@ def sa_wide_scale_infer(xyz, new_xyz, feats_pm, idx, folded):
         pointnet2.sa_point_gather(rows, xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), w1, y1, B, N, M, ns, c1, bias=b1, relu=True)
         y2 = _gemm_nt(y1, w2, b2, relu=True)
         del y1
+        if ns in (16, 32, 64) and c2 % 32 == 0:
+            # the max over nsample in the epilogue of the last contraction: (T, c3) is never written
+            pooled = torch.empty((B, M, c3), dtype=torch.float32, device=xyz.device)
+            pointnet2.gemm_split_maxpool(y2, _split_planes(w3), b3.detach().contiguous(), pooled, T, c2, c3, ns, relu=True)
+            out.append(pooled)
+            return
         y3 = _gemm_nt(y2, w3, b3, relu=True)
         del y2
         out.append(y3.view(B, M, ns, c3).amax(dim=2))

@@ -99,3 +99,24 @@ def test_narrow_and_short_problems_stay_on_the_library():
         assert torch.allclose(y, torch.relu(torch.nn.functional.linear(x, w, b)), atol=1e-4, rtol=1e-4)
         gx = pu._gemm_nn(y, w)
         assert torch.allclose(gx, y @ w, atol=2e-3, rtol=1e-4)
+
+
+@pytest.mark.parametrize("groups,ns,K,N", [(2048, 16, 256, 512), (1031, 32, 512, 384), (777, 64, 256, 256), (5, 16, 64, 128)])
+def test_maxpool_epilogue_equals_gemm_then_max(groups, ns, K, N):
+    """pda_gemm_split_maxpool (the max over nsample in the epilogue of the last SA contraction, inference) against pda_gemm_split
+    followed by the max: the same arithmetic, bit for bit, including a ragged last tile and an odd number of 128-column chunks."""
+    from pdanet_amd import pointnet2_batch_cuda as ext
+    T = groups * ns
+    g = torch.Generator("cuda").manual_seed(groups + ns)
+    x = torch.randn(T, K, device="cuda", generator=g)
+    w = torch.randn(N, K, device="cuda", generator=g) * 0.1
+    bias = torch.randn(N, device="cuda", generator=g)
+    wf = ext.linear_split_pack(w, N, K)
+    y = torch.empty(T, N, device="cuda")
+    ext.gemm_split(x, wf, bias, y, T, K, N, relu=True)
+    want = y.view(groups, ns, N).amax(dim=1)
+    out = torch.full((groups, N), float("nan"), device="cuda")
+    ext.gemm_split_maxpool(x, wf, bias, out, T, K, N, ns, relu=True)
+    assert torch.equal(out, want)
+    with pytest.raises(Exception):
+        ext.gemm_split_maxpool(x, wf, bias, out, T, K, N, 24)
