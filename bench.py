@@ -202,6 +202,8 @@ def main():
         line["config"]["graph_head"] = bool(getattr(wl.model, "graph_head", False))
         if hasattr(wl, "host_bound"):
             line["config"]["host_bound_at_probe"] = bool(wl.host_bound)
+    if hasattr(getattr(wl, "model", None), "graph_tail_infer"):
+        line["config"]["graph_tail_infer"] = bool(wl.model.graph_tail_infer)     # inference: layers 3-5 replayed as one hipGraph
 
     single = world == 1 and rank == 0
     if single and not args.no_cpu_baseline:
@@ -232,6 +234,8 @@ def main():
                                 "dtype": xw.dtype}
                 if xname == "backbone_infer" and xr.get("roofline") is not None:
                     extra[xname]["roofline_mfma_fused_sa"] = xr["roofline"]
+                if xname == "backbone_infer":
+                    extra[xname]["graph_tail_infer"] = bool(getattr(xw.model, "graph_tail_infer", False))
                 del xw
             except Exception as e:  # noqa: BLE001  (a secondary timing must not cost the headline line)
                 print("bench.py: extra workload %s failed: %r" % (xname, e), file=sys.stderr)

@@ -125,6 +125,13 @@ int pda_gemm_split_bn(const float *x, const void *wf, float *y, int64_t tokens, 
  * tokens a multiple of ns, K a multiple of 32.  Same arithmetic as pda_gemm_split followed by the max. */
 int pda_gemm_split_maxpool(const float *x, const void *wf, const float *bias, float *out, int64_t tokens, int k, int n_out,
                            int ns, int relu, pda_stream_t stream);
+/* Inference: the first two layers of a wide SA scale in one launch.  y (b*m*ns, n_out) = relu?(A W2^T + bias2) with
+ * A[token] = relu(point_rows[idx[token]] + W1[:, 0:3] (xyz[idx[token]] - new_xyz[group]) + bias1) -- what pda_sa_point_gather would
+ * write -- formed in the operand load.  point_rows (b*n, K): the per-point projection of the features by W1[:, 3:]; w1 (K, ldw1);
+ * wf: pda_linear_split_pack planes of W2 (n_out, K).  K a multiple of 32 <= 1024. */
+int pda_gemm_split_gather(const float *point_rows, const float *xyz, const float *new_xyz, const int32_t *idx,
+                          const float *w1, int ldw1, const float *bias1, const void *wf, const float *bias2, float *y,
+                          int b, int n, int m, int ns, int k, int n_out, int relu, pda_stream_t stream);
 /* The passes of pda_bn_relu_fwd / pda_bn_relu_max_pool_fwd one at a time.  pda_bn_stats_fwd: statistics of x only
  * (mean_invstd (2, C), running statistics updated); scratch: pda_bn_relu_scratch_bytes(c).  pda_bn_finalize_fwd: the same
  * from `nblocks` rows of per-block sums [nblocks][2][C] (count = the number of rows they cover).

@@ -84,6 +84,7 @@ SIGNATURES = {
     "pda_gemm_split_bn_tiles": [ctypes.c_int64],
     "pda_gemm_split_bn": [_vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp, _vp, _vp, _i, _vp, _vp],
     "pda_gemm_split_maxpool": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _i, _vp],
+    "pda_gemm_split_gather": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
     "pda_bn_stats_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp],
     "pda_bn_finalize_fwd": [_vp, _i, _i, ctypes.c_int64, _f, _f, _vp, _vp, _vp, _vp],
     "pda_bn_relu_max_pool_apply": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],

@@ -80,6 +80,11 @@ class IASSD_Backbone(nn.Module):
         self.prefetch_sampling = True
         self._side_stream = None
         self._prefetched = []          # FIFO of (key, presampled) started by prefetch(), oldest first, at most two
+        # Inference (eval, no_grad): the layers behind the last host read of a token count (first_static_tail_layer: ONCE
+        # layers 3, 4, 5 -- static shapes, ~100 launches) replayed as ONE hipGraph.  The tensors they return are the graph's
+        # own buffers: valid until the next forward.  Off by default; bench.py's inference workload switches it on.
+        self.graph_tail_infer = False
+        self._tail_graph = None
 
     def _presample(self, xyz, points=None, batch_size=None, limit=None):
         """Sampling of the leading layers that need only coordinates (identity / D-FPS, chained
@@ -190,9 +195,66 @@ class IASSD_Backbone(nn.Module):
 
     def _forward(self, batch_dict):
         st = self._begin(batch_dict)
-        for i in range(len(self.SA_modules)):
+        n = len(self.SA_modules)
+        i0 = n
+        if (self.graph_tail_infer and not self.training and not torch.is_grad_enabled() and st['encoder_xyz'][0].is_cuda
+                and not torch.cuda.is_current_stream_capturing()):
+            i0 = self.first_static_tail_layer()
+            if i0 < 1 or any(self._layer_reads_before(i, i0) for i in range(i0, n)):
+                i0 = n
+        for i in range(i0):
             self._run_layer(i, st)
+        if i0 < n:
+            self._run_tail_graphed(i0, st)
         return self._finish(batch_dict, st)
+
+    def _layer_reads_before(self, i, i0):
+        # state index k + 1 holds the output of layer k (index 0: the raw points)
+        reads = [self.layer_inputs[i]] if not isinstance(self.layer_inputs[i], list) else list(self.layer_inputs[i])
+        if self.layer_types[i] == 'SA_Layer' and self.ctr_idx_list[i] != -1:
+            reads.append(self.ctr_idx_list[i])
+        return any(r < i0 for r in reads)
+
+    def _run_tail_graphed(self, i0, st):
+        """Layers i0.. of an inference forward as one hipGraph replay (captured on first use per input shape and per state
+        of the weights).  Inputs are copied into the graph's buffers (three small tensors); the outputs stay in them."""
+        from . import _lib
+        n = len(self.SA_modules)
+        xyz, feats, cls, bidx = st['encoder_xyz'][i0], st['encoder_features'][i0], st['li_cls_pred'], st['bidx']
+        tail_params = [p for i in range(i0, n) for p in self.SA_modules[i].parameters()]
+        key = (i0, st['batch_size'], tuple(xyz.shape), tuple(feats.shape), None if cls is None else tuple(cls.shape), tuple(bidx.shape),
+               _lib.PARAM_EPOCH[0], _lib.WEIGHT_EPOCH[0], tuple(p._version for p in tail_params), tuple(p.data_ptr() for p in tail_params[:4]))
+        if self._tail_graph is None or self._tail_graph[0] != key:
+            sx, sf, sb = xyz.clone(), feats.clone(), bidx.clone()
+            sc = None if cls is None else cls.clone()
+
+            def run():
+                st2 = dict(batch_size=st['batch_size'], encoder_xyz=[None] * i0 + [sx], encoder_features=[None] * i0 + [sf],
+                           sa_ins_preds=[], sample_ids=[], encoder_coords=[], bidx=sb, li_cls_pred=sc, presampled={})
+                for i in range(i0, n):
+                    self._run_layer(i, st2)
+                return st2
+            side = torch.cuda.Stream(device=xyz.device)
+            side.wait_stream(torch.cuda.current_stream(xyz.device))
+            with torch.cuda.stream(side):
+                run()                                   # warm-up outside the capture: caches (folded BatchNorm, packed planes) fill here
+            torch.cuda.current_stream(xyz.device).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, capture_error_mode="thread_local"):
+                st2 = run()
+            self._tail_graph = (key, graph, (sx, sf, sc, sb), st2)
+        _, graph, (sx, sf, sc, sb), st2 = self._tail_graph
+        sx.copy_(xyz); sf.copy_(feats); sb.copy_(bidx)
+        if sc is not None:
+            sc.copy_(cls)
+        graph.replay()
+        for k in ('encoder_xyz', 'encoder_features'):
+            st[k] = st[k][:i0 + 1] + st2[k][i0 + 1:]
+        for k in ('sa_ins_preds', 'sample_ids', 'encoder_coords'):
+            st[k] = st[k] + st2[k]
+        for k in ('centers', 'centers_origin', 'ctr_offsets', 'li_cls_pred'):
+            if k in st2:
+                st[k] = st2[k]
 
     # ---- the forward pass as explicit steps over a state dict (detector.IASSD replays a static tail as hipGraphs) ------
     def _begin(self, batch_dict, first_graphed=None):

@@ -248,6 +248,14 @@ struct GemmSplitParams {
     const float* in_b;      //      (K) beta
     double* partial;        // EPI 1: [token tile][2][n_out] per-column sum / sum of squares of this launch's output
     int pool_ns;            // EPI 2: y is (tokens / pool_ns, n_out), the max over each group of pool_ns consecutive token rows
+    // PRO 2 (inference): X row of token t = relu(P[scene(t) * gn + idx[t]] + W_xyz (xyz[idx[t]] - centre(t)) + bias): the first layer
+    // of a wide SA scale (sa_point_gather_kernel, csrc/sa_xyz_grad.hip) formed in the operand load.  x = P (b * gn, K) rows.
+    const int32_t* g_idx;   // (tokens)
+    const float* g_xyz;     // (b, gn, 3)
+    const float* g_ctr;     // (tokens / g_ns, 3)
+    const float* g_w;       // first-layer weight (K, g_ldw): columns 0..2 are the coordinates'
+    const float* g_bias;    // (K)
+    int gn, g_ns, g_m, g_ldw;
 };
 
 constexpr int GT_XCHUNKS = 128 * 4;                  // uint4 per X tile (128 rows x 64 bytes)
@@ -412,6 +420,15 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
     // producer sources
     const int64_t ptok = tok0 + 32 * w + r < p.tokens ? tok0 + 32 * w + r : p.tokens - 1;
     const float* xsrc = p.x + ptok * p.k + 8 * h;
+    float gdx = 0.f, gdy = 0.f, gdz = 0.f;                            // PRO 2: this lane's token relative to its centre
+    if constexpr (PRO == 2) {
+        const int64_t grp = ptok / p.g_ns;
+        const int64_t prow = (grp / p.g_m) * p.gn + p.g_idx[ptok];
+        xsrc = p.x + prow * p.k + 8 * h;
+        const float* pt = p.g_xyz + prow * 3;
+        const float* ct = p.g_ctr + grp * 3;
+        gdx = pt[0] - ct[0]; gdy = pt[1] - ct[1]; gdz = pt[2] - ct[2];      // pointnet2_utils.py:692
+    }
     const uint4* wsrc[NP];
 #pragma unroll
     for (int e = 0; e < NP; ++e) {
@@ -433,11 +450,23 @@ void gemm_split_wide_kernel(const GemmSplitParams p) {
     uint4* const my_w = gp_planes + XF * 192 + (NP * w) * 64 + lane;    // + buffer * TILE_U4 + e * 64
     // PRO: {mean, invstd, gamma, beta} of input channel k at cst[k]
     float4* const cst = reinterpret_cast<float4*>(gp_planes + 2 * TILE_U4);
-    if constexpr (PRO) {
+    if constexpr (PRO == 1) {
         for (int k = tid; k < p.k; k += 512) cst[k] = make_float4(p.in_mi[k], p.in_mi[p.k + k], p.in_g[k], p.in_b[k]);
         __syncthreads();
     }
-    auto bnrelu = [&](float x, const float4& c) { return fmaxf((x - c.x) * c.y * c.z + c.w, 0.f); };
+    if constexpr (PRO == 2) {
+        for (int k = tid; k < p.k; k += 512) {
+            const float* wr = p.g_w + (size_t)k * p.g_ldw;
+            cst[k] = make_float4(wr[0], wr[1], wr[2], p.g_bias ? p.g_bias[k] : 0.f);
+        }
+        __syncthreads();
+    }
+    auto bnrelu = [&](float x, const float4& c) {
+        if constexpr (PRO == 2)      // sa_point_gather_kernel's expression, bit for bit
+            return fmaxf(__builtin_fmaf(c.z, gdz, __builtin_fmaf(c.y, gdy, __builtin_fmaf(c.x, gdx, x))) + c.w, 0.f);
+        else
+            return fmaxf((x - c.x) * c.y * c.z + c.w, 0.f);
+    };
     const float4* const my_cst = cst + 8 * h;                           // + 16 * step + j
     gs_f32x16 acc[2][4];
 #pragma unroll
@@ -807,4 +836,34 @@ PDA_API int pda_gemm_split_maxpool(const float* x, const void* wf, const float* 
     PDA_REQUIRE(ok, "pda_gemm_split_maxpool: dynamic LDS refused");
     hipLaunchKernelGGL((pda::gemm_split_wide_kernel<0, 2>), dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16, (hipStream_t)stream, p);
     return pda::check_launch("pda_gemm_split_maxpool");
+}
+
+// Inference, the first two layers of a wide SA scale in one launch: y (tokens, n_out) = relu?(A W2^T + bias2) with
+// A[token] = relu(P[idx[token]] + W1_xyz (xyz[idx[token]] - centre) + bias1) formed in the operand load (what pda_sa_point_gather
+// would write).  point_rows (b * n, K) = the per-point projection of the features; w1 (K, ldw1) the first layer's weight.
+PDA_API int pda_gemm_split_gather(const float* point_rows, const float* xyz, const float* new_xyz, const int32_t* idx, const float* w1, int ldw1,
+                                  const float* bias1, const void* wf, const float* bias2, float* y, int b, int n, int m, int ns, int k, int n_out,
+                                  int relu, pda_stream_t stream) {
+    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && ns >= 1 && k > 0 && n_out > 0 && ldw1 >= 3, "pda_gemm_split_gather: bad size");
+    const int64_t tokens = (int64_t)b * m * ns;
+    if (tokens == 0) return PDA_OK;
+    PDA_REQUIRE(point_rows && xyz && new_xyz && idx && w1 && wf && y && (((uintptr_t)point_rows | (uintptr_t)wf) & 15) == 0,
+                "pda_gemm_split_gather: null or misaligned pointer");
+    if (k % 32 != 0 || k > 1024) {
+        pda::set_error("pda_gemm_split_gather: no kernel built for K=%d (a multiple of 32, <= 1024)", k);
+        return PDA_ERR_UNSUPPORTED;
+    }
+    pda::GemmSplitParams p{};
+    p.x = point_rows; p.wf = (const uint4*)wf; p.bias = bias2; p.y = y; p.tokens = tokens; p.k = k; p.n_out = n_out;
+    p.chunks = pda::divup(n_out, 128); p.ksteps = k / 16; p.relu = relu;
+    p.g_idx = idx; p.g_xyz = xyz; p.g_ctr = new_xyz; p.g_w = w1; p.g_bias = bias1; p.gn = n; p.g_ns = ns; p.g_m = m; p.g_ldw = ldw1;
+    const int64_t wide_blocks = pda::divup64(tokens, 256) * ((p.chunks + 1) / 2);
+    PDA_REQUIRE(wide_blocks < (1ll << 31), "pda_gemm_split_gather: too many tiles");
+    static pda::PerDevice<bool> lds_ok;
+    const bool ok = lds_ok.get([] { return hipFuncSetAttribute((const void*)pda::gemm_split_wide_kernel<2, 0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                               2 * pda::GW_TILE_U4 * 16 + 1024 * 16) == hipSuccess; });
+    PDA_REQUIRE(ok, "pda_gemm_split_gather: dynamic LDS refused");
+    hipLaunchKernelGGL((pda::gemm_split_wide_kernel<2, 0>), dim3((unsigned)wide_blocks), dim3(512), 2 * pda::GW_TILE_U4 * 16 + k * 16,
+                       (hipStream_t)stream, p);
+    return pda::check_launch("pda_gemm_split_gather");
 }

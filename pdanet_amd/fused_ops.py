@@ -82,7 +82,7 @@ class FusedSAMlp:
         arr = lambda ts: (ctypes.c_void_p * 3)(*[t.data_ptr() for t in ts])
         assert xyz.is_contiguous() and new_xyz.is_contiguous() and idx.is_contiguous()
         assert features is None or (features.is_contiguous() and features.dtype == torch.float32)
-        prof = PROFILE
+        prof = None if torch.cuda.is_current_stream_capturing() else PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

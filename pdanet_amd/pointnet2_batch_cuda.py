@@ -470,6 +470,21 @@ def gemm_split_maxpool(x, wf, bias, out, tokens, k, n_out, ns, relu=True):
     return 1
 
 
+def gemm_split_gather(point_rows, xyz, new_xyz, idx, w1, bias1, wf, bias2, y, b, n, m, ns, k, n_out, relu=True):
+    """y (b*m*ns, n_out) = relu?(A W2^T + bias2), A = the first SA layer's output formed in the operand load from the per-point
+    projection `point_rows` (b*n, k), the neighbour lists and the coordinate columns of w1 (k, 3 + c) (include/pda_train.h)."""
+    t = b * m * ns
+    _numel_ok(point_rows, b * n * k, "point_rows"); _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz")
+    _numel_ok(idx, t, "idx"); _numel_ok(y, t * n_out, "y"); _numel_ok(wf, _split_packed_bytes(int(n_out), int(k)), "wf")
+    if w1.dim() != 2 or w1.shape[0] != k or w1.shape[1] < 3:
+        raise RuntimeError("w1 must be (k, 3 + c)")
+    _call("pda_gemm_split_gather", y, _chk(point_rows, "point_rows", F32), _chk(xyz, "xyz", F32), _chk(new_xyz, "new_xyz", F32),
+          _chk(idx, "idx", I32), _chk(w1, "w1", F32), int(w1.shape[1]), None if bias1 is None else _chk(bias1, "bias1", F32),
+          _chk(wf, "wf", torch.uint8), None if bias2 is None else _chk(bias2, "bias2", F32), _chk(y, "y", F32), b, n, m, ns, k, n_out,
+          1 if relu else 0)
+    return 1
+
+
 def bn_stats_fwd(x, running_mean, running_var, mean_invstd, scratch, rows, c, eps, momentum):
     """The statistics pass of bn_relu_fwd alone (mean_invstd (2, C); running statistics updated)."""
     _numel_ok(x, rows * c, "x"); _numel_ok(mean_invstd, 2 * c, "mean_invstd")

@@ -923,7 +923,7 @@ SA_MFMA_EVENTS = None      # bench: a list collecting (event0, event1, flops, pi
 def _sa_timed(flops, fn, pipe="f32"):
     """pipe: "f32" = v_mfma_f32_32x32x2_f32, "bf16x6" = six v_mfma_f32_32x32x16_bf16 per f32 product block (split GEMMs)."""
     ev = SA_MFMA_EVENTS
-    if ev is None:
+    if ev is None or torch.cuda.is_current_stream_capturing():     # (a timing event inside a capture is a node, not a clock)
         return fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -1100,6 +1100,7 @@ class SaPointLinear(Function):
 
 
 SA_WIDE_INFER_SPLIT = os.environ.get("PDA_SA_WIDE_INFER_SPLIT", "1") != "0"
+SA_WIDE_INFER_GATHER_IN_GEMM = os.environ.get("PDA_SA_WIDE_INFER_GATHER_IN_GEMM", "1") != "0"
 
 
 def sa_wide_scale_infer(xyz, new_xyz, feats_pm, idx, folded):
@@ -1120,10 +1121,16 @@ def sa_wide_scale_infer(xyz, new_xyz, feats_pm, idx, folded):
 
     def run():
         rows = _gemm_nt(feats_pm.reshape(B * N, C), w1[:, 3:].contiguous())
-        y1 = torch.empty((T, c1), dtype=torch.float32, device=xyz.device)
-        pointnet2.sa_point_gather(rows, xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), w1, y1, B, N, M, ns, c1, bias=b1, relu=True)
-        y2 = _gemm_nt(y1, w2, b2, relu=True)
-        del y1
+        if SA_WIDE_INFER_GATHER_IN_GEMM and c1 % 32 == 0 and c1 <= 1024:
+            # the first layer's output is formed in the operand load of the second contraction: (T, c1) is never written
+            y2 = torch.empty((T, c2), dtype=torch.float32, device=xyz.device)
+            pointnet2.gemm_split_gather(rows, xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), w1.contiguous(), b1.detach().contiguous(),
+                                        _split_planes(w2), b2.detach().contiguous(), y2, B, N, M, ns, c1, c2, relu=True)
+        else:
+            y1 = torch.empty((T, c1), dtype=torch.float32, device=xyz.device)
+            pointnet2.sa_point_gather(rows, xyz.contiguous(), new_xyz.contiguous(), idx.contiguous(), w1, y1, B, N, M, ns, c1, bias=b1, relu=True)
+            y2 = _gemm_nt(y1, w2, b2, relu=True)
+            del y1
         if ns in (16, 32, 64) and c2 % 32 == 0:
             # the max over nsample in the epilogue of the last contraction: (T, c3) is never written
             pooled = torch.empty((B, M, c3), dtype=torch.float32, device=xyz.device)
@@ -1231,6 +1238,7 @@ def sa_small_chain_train(xyz, new_xyz, feats_pm, idx, mlp):
 # measured too: reading z tile by tile behind a 256 x 256 tile's stores costs more than the standalone pass, +0.23 ms on
 # 131072 x 512 x 512 against 0.10 ms, and was removed.)
 SA_WIDE_CHAIN = os.environ.get("PDA_SA_WIDE_CHAIN", "1") != "0"
+WIDE_CHAIN_DGRAD_FIRST = os.environ.get("PDA_WIDE_CHAIN_DGRAD_FIRST", "1") != "0"
 SA_WIDE_CHAIN_MIN_TOKENS = int(os.environ.get("PDA_SA_WIDE_CHAIN_MIN_TOKENS", "32768"))   # (at 32768 tokens the 256 x 256 tiles take 50 us against lin_split's 35 and the passes saved are still worth more; at 16384 they are not)
 
 
@@ -1319,9 +1327,13 @@ class SaWideChainTrain(Function):
             def layer(gz, w, z_in, mi_in, gi, bi, k_in, n_out):
                 """gz (T, n_out) = gradient at this layer's output z; returns (dW, gradient at z_in, dgamma_in, dbeta_in)."""
                 dw = torch.empty((n_out, k_in), dtype=torch.float32, device=dev)
-                pointnet2.linear_wgrad_bn(z_in, gz, dw, T, k_in, n_out, mi_in, gi, bi)
                 ga = torch.empty((T, k_in), dtype=torch.float32, device=dev)
-                _lin_cols(gz, w, ga, T, n_out, k_in, True)                                    # ga = gz W (timed as a bf16x6 launch)
+                if WIDE_CHAIN_DGRAD_FIRST:
+                    _lin_cols(gz, w, ga, T, n_out, k_in, True)                                # ga = gz W (timed as a bf16x6 launch)
+                    pointnet2.linear_wgrad_bn(z_in, gz, dw, T, k_in, n_out, mi_in, gi, bi)
+                else:
+                    pointnet2.linear_wgrad_bn(z_in, gz, dw, T, k_in, n_out, mi_in, gi, bi)
+                    _lin_cols(gz, w, ga, T, n_out, k_in, True)
                 dg, db = torch.empty_like(gi), torch.empty_like(bi)
                 scratch = torch.empty((pointnet2.bn_relu_scratch_bytes(k_in),), dtype=torch.uint8, device=dev)
                 pointnet2.bn_relu_bwd(z_in, ga, gi, bi, mi_in, ga, dg, db, scratch, T, k_in)   # in place: a thread reads what it writes

@@ -120,3 +120,28 @@ def test_maxpool_epilogue_equals_gemm_then_max(groups, ns, K, N):
     assert torch.equal(out, want)
     with pytest.raises(Exception):
         ext.gemm_split_maxpool(x, wf, bias, out, T, K, N, 24)
+
+
+@pytest.mark.parametrize("B,N,M,ns,c1,c2", [(2, 2048, 1024, 32, 256, 256), (1, 700, 130, 16, 256, 512), (2, 1024, 200, 64, 512, 384)])
+def test_gather_in_operand_load_equals_gather_then_gemm(B, N, M, ns, c1, c2):
+    """pda_gemm_split_gather (inference: the first SA layer's output formed in the operand load of the second contraction)
+    against pda_sa_point_gather followed by pda_gemm_split: the same arithmetic, bit for bit."""
+    from pdanet_amd import pointnet2_batch_cuda as ext, pointnet2_utils as pu, synth
+    g = torch.Generator("cuda").manual_seed(B + N + ns)
+    xyz = torch.from_numpy(synth.batch_xyz(B, N, config_id=6)).cuda()
+    ctr = (xyz[:, :M] + 0.1).contiguous()
+    idx = pu.ball_query(8.4, ns, xyz, ctr)
+    rows = torch.randn(B * N, c1, device="cuda", generator=g)
+    w1 = torch.randn(c1, 3 + 64, device="cuda", generator=g) * 0.2
+    b1 = torch.randn(c1, device="cuda", generator=g) * 0.3
+    w2 = torch.randn(c2, c1, device="cuda", generator=g) * 0.1
+    b2 = torch.randn(c2, device="cuda", generator=g)
+    T = B * M * ns
+    y1 = torch.empty(T, c1, device="cuda")
+    ext.sa_point_gather(rows, xyz, ctr, idx, w1, y1, B, N, M, ns, c1, bias=b1, relu=True)
+    wf = ext.linear_split_pack(w2, c2, c1)
+    want = torch.empty(T, c2, device="cuda")
+    ext.gemm_split(y1, wf, b2, want, T, c1, c2, relu=True)
+    got = torch.full((T, c2), float("nan"), device="cuda")
+    ext.gemm_split_gather(rows, xyz, ctr, idx, w1, b1, wf, b2, got, B, N, M, ns, c1, c2, relu=True)
+    assert torch.equal(got, want)

@@ -325,3 +325,40 @@ def test_backbone_prefetch_starts_the_next_forward_early_and_changes_nothing():
         assert torch.equal(a, b)
     for a, b in zip(ref_other, got_other):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_inference_graph_tail_equals_eager_forward():
+    """IASSD_Backbone.graph_tail_infer (eval, no_grad: the layers behind the last token-count read replayed as one hipGraph)
+    against the launch-by-launch forward: every output bit for bit, over three different batches (the graph's buffers are
+    refilled), and again after the weights changed (a new capture)."""
+    from pdanet_amd import fused_ops, synth
+    from pdanet_amd.backbone import build_backbone
+    torch.manual_seed(3)
+    model, _ = build_backbone("once_pda_ssd.yaml")
+    model = model.cuda().eval()
+    fused_ops.enable_fused(model)
+    B, N = 2, 16384
+    keys = ("centers_features", "centers", "centers_origin", "ctr_offsets")
+
+    def fwd(pts, graphed):
+        model.graph_tail_infer = graphed
+        with torch.no_grad():
+            bd = model({'batch_size': B, 'points': pts})
+        out = {k: bd[k].clone() for k in keys}
+        out.update({"xyz%d" % i: t.clone() for i, t in enumerate(bd['encoder_xyz'])})
+        out.update({"f%d" % i: t.clone() for i, t in enumerate(bd['encoder_features']) if t is not None})
+        out.update({"c%d" % i: t.clone() for i, t in enumerate(bd['encoder_coords'])})
+        out.update({"p%d" % i: t.clone() for i, t in enumerate(bd['sa_ins_preds']) if torch.is_tensor(t)})
+        return out
+    for rnd in range(2):
+        for seed in (2, 12, 22):
+            pts = torch.from_numpy(synth.batch_points(B, N, config_id=seed, dist="L")).cuda()
+            a, b = fwd(pts, True), fwd(pts, False)
+            assert set(a) == set(b)
+            for k in b:
+                assert torch.equal(a[k], b[k]), (rnd, seed, k)
+        with torch.no_grad():                       # new weights: the captured graph must not be replayed with the old ones
+            for p in model.SA_modules[5].parameters():
+                p.mul_(1.01)
+    assert model._tail_graph is not None
