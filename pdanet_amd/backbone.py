@@ -224,7 +224,11 @@ class IASSD_Backbone(nn.Module):
         tail_params = [p for i in range(i0, n) for p in self.SA_modules[i].parameters()]
         key = (i0, st['batch_size'], tuple(xyz.shape), tuple(feats.shape), None if cls is None else tuple(cls.shape), tuple(bidx.shape),
                _lib.PARAM_EPOCH[0], _lib.WEIGHT_EPOCH[0], tuple(p._version for p in tail_params), tuple(p.data_ptr() for p in tail_params[:4]))
-        if self._tail_graph is None or self._tail_graph[0] != key:
+        if self._tail_graph is None:
+            self._tail_graph = {}
+        if key not in self._tail_graph:
+            if len(self._tail_graph) >= 4:                  # a few input shapes in rotation at most; stale weights' graphs go first
+                self._tail_graph.pop(next(iter(self._tail_graph)))
             sx, sf, sb = xyz.clone(), feats.clone(), bidx.clone()
             sc = None if cls is None else cls.clone()
 
@@ -242,8 +246,8 @@ class IASSD_Backbone(nn.Module):
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, capture_error_mode="thread_local"):
                 st2 = run()
-            self._tail_graph = (key, graph, (sx, sf, sc, sb), st2)
-        _, graph, (sx, sf, sc, sb), st2 = self._tail_graph
+            self._tail_graph[key] = (graph, (sx, sf, sc, sb), st2)
+        graph, (sx, sf, sc, sb), st2 = self._tail_graph[key]
         sx.copy_(xyz); sf.copy_(feats); sb.copy_(bidx)
         if sc is not None:
             sc.copy_(cls)
