@@ -721,6 +721,227 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
         if (kk[i] >= 0) temp[kk[i]] = tp[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// fps_chain_coop_kernel<P>: the cooperative form (K workgroups per scene, 24576 < N <= 65536) with SEVERAL samples per
+// exchange.  fps_pruned_kernel<P, true> exchanges one winner per round: 16383 rounds of ~2.1 us for 60000 -> 16384, the
+// shipped ONCE input (34.5 ms: twice the rest of the training iteration).  Here every workgroup keeps the 64 row records
+// of fps_chain_kernel for its own quarter of the cloud, publishes all of them once per synchronisation (6 x 64 tagged
+// 8-byte granules), collects the 64 K records of the scene, and wave 0 of EVERY workgroup walks them -- the same data and
+// the same deterministic instructions in each, so all K workgroups decide the same chain without a second exchange.  The
+// acceptance rule and its proof are fps_chain_kernel's (a record = any set of points with its best point, best value and
+// second-best value; which workgroup owns the row does not matter); the exchange, its bounded polls and the failure model
+// are fps_pruned_kernel<P, true>'s (a timeout marks the scene, every workgroup stops, fps_recover_kernel recomputes it).
+// Indices and the final temp are bit-identical to the reference.
+constexpr int FPS_CC_WORDS = 6;                   // value, T, x, y, z, second-best value
+constexpr int FPS_CC_GRANULES = FPS_RECORDS * FPS_CC_WORDS;      // per workgroup and synchronisation
+__device__ unsigned long long g_fps_cbuf[FPS_XBUF_REGIONS * FPS_XBUF_SCENES * 2 * FPS_MAX_K * FPS_CC_GRANULES];
+
+template <int P>
+__global__ __launch_bounds__(FPS_THREADS) void fps_chain_coop_kernel(const float* __restrict__ xyz_all, float* __restrict__ temp_all,
+                                                                      int32_t* __restrict__ idx_all, int n_total, int m, int L,
+                                                                      int K, int nb, uint32_t epoch) {
+    constexpr int NS = FPS_THREADS * P;
+    __shared__ uint32_t skey[NS];            // the sort's keys; behind the set-up: the records of all K workgroups
+    __shared__ float red[FPS_WAVES * 6];
+    __shared__ uint32_t rec[FPS_CC_GRANULES];   // my 64 records, [row][word]
+    __shared__ float4 chain[FPS_CHAIN_MAX];
+    __shared__ int chain_n, failflag;
+    const int t = threadIdx.x;
+    const int lane = lane_id();
+    const int w = wave_id();
+    const int scene = (int)(blockIdx.x % nb), g = (int)(blockIdx.x / nb);
+    const int nper = (n_total + K - 1) / K;
+    const int k_lo = g * nper;
+    const int n = max(0, min(n_total, k_lo + nper) - k_lo);
+    const float* __restrict__ xyz0 = xyz_all + (size_t)scene * n_total * 3;
+    const float* __restrict__ xyz = xyz0 + (size_t)k_lo * 3;
+    float* __restrict__ temp = temp_all + (size_t)scene * n_total + k_lo;
+    int32_t* __restrict__ idx = idx_all + (size_t)scene * m;
+    const int spin_limit = g_fps_spin_limit;
+
+    uint32_t kT[P];
+    float px[P], py[P], pz[P], tp[P];
+    float blo[3], bhi[3];
+    float lbest;
+    int bi;
+    uint16_t* const kk_lds = reinterpret_cast<uint16_t*>(skey + NS / 2);     // upper half of skey, behind the set-up
+    {
+        int kk[P];
+        fps_sorted_setup<P>(xyz, temp, n, k_lo, L, skey, red, px, py, pz, tp, kT, kk, blo, bhi, lbest, bi);
+        __syncthreads();                      // everyone is done with skey
+        // the points' local indices are needed again only for the final store of temp: 16 registers a lane does not have to
+        // carry through 1600 synchronisations (the walk's 24 record registers come on top of the 96 of the points)
+#pragma unroll
+        for (int i = 0; i < P; ++i) kk_lds[i * FPS_THREADS + t] = (uint16_t)(kk[i] >= 0 ? kk[i] : 0xffff);
+    }
+    uint32_t* const allrec = skey;            // [workgroup q][row][word]: 6 K x 256 bytes at the bottom of skey
+
+    if (t == 0) {
+        if (g == 0) idx[0] = 0;
+        chain[0] = make_float4(xyz0[0], xyz0[1], xyz0[2], 0.f);   // sample 0 = point 0 of the SCENE
+        chain_n = 1;
+        failflag = 0;
+    }
+    if (t < FPS_CC_GRANULES) rec[t] = (t % FPS_CC_WORDS == 1) ? 0xffffffffu : __builtin_bit_cast(uint32_t, -1.f);   // inert until refreshed
+    __syncthreads();
+    int j = 1, cn = 1;
+    bool dirty = true;
+    uint32_t sync = 0;
+    while (true) {
+        // ---- apply the chain to my points (fps_chain_kernel's phase, unchanged) ----
+        const int napply = min(cn, (m - 1) - (j - cn));
+        bool scanned = dirty;
+        for (int c = 0; c < napply; ++c) {
+            const float4 s4 = chain[c];
+            const float ex = fmaxf(fmaxf(blo[0] - s4.x, s4.x - bhi[0]), 0.f);
+            const float ey = fmaxf(fmaxf(blo[1] - s4.y, s4.y - bhi[1]), 0.f);
+            const float ez = fmaxf(fmaxf(blo[2] - s4.z, s4.z - bhi[2]), 0.f);
+            const float dbox = __builtin_fmaf(ez, ez, __builtin_fmaf(ey, ey, ex * ex));
+            const bool hit = dbox * 0.9999f < lbest;
+            if (__ballot(hit) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < P; ++i) tp[i] = fminf(sqdist3(px[i], py[i], pz[i], s4.x, s4.y, s4.z), tp[i]);
+                scanned = true;
+            }
+        }
+        if (scanned) {
+            float bv[P], sv[P];
+            int bx[P];
+#pragma unroll
+            for (int i = 0; i < P; ++i) { bv[i] = tp[i]; bx[i] = i; sv[i] = -1.f; }
+#pragma unroll
+            for (int st = 1; st < P; st <<= 1)
+#pragma unroll
+                for (int i = 0; i + st < P; i += 2 * st) {
+                    const bool gt = bv[i + st] > bv[i];
+                    sv[i] = fmaxf(fmaxf(sv[i], sv[i + st]), fminf(bv[i], bv[i + st]));
+                    bx[i] = gt ? bx[i + st] : bx[i];
+                    bv[i] = fmaxf(bv[i], bv[i + st]);
+                }
+            lbest = bv[0]; bi = bx[0];
+            const float lsec = sv[0];
+            float mx = px[0], my = py[0], mz = pz[0];
+            uint32_t mT = kT[0];
+#pragma unroll
+            for (int i = 1; i < P; ++i) {
+                const bool sel = bi == i;
+                mx = sel ? px[i] : mx; my = sel ? py[i] : my; mz = sel ? pz[i] : mz; mT = sel ? kT[i] : mT;
+            }
+            const float rmax = row_allmax_f32(lbest);
+            const uint32_t rT = row_allmin_u32(lbest == rmax ? mT : 0xffffffffu);
+            const bool iswin = lbest == rmax && mT == rT;
+            const float rsec = row_allmax_f32(iswin ? lsec : lbest);
+            if (iswin) {
+                uint32_t* r = rec + (t >> 4) * FPS_CC_WORDS;
+                r[0] = __builtin_bit_cast(uint32_t, lbest); r[1] = mT;
+                r[2] = __builtin_bit_cast(uint32_t, mx); r[3] = __builtin_bit_cast(uint32_t, my); r[4] = __builtin_bit_cast(uint32_t, mz);
+                r[5] = __builtin_bit_cast(uint32_t, rsec);
+            }
+            dirty = false;
+        }
+        if (j >= m) break;
+        lds_barrier();
+        // ---- exchange: publish my 64 records, collect the scene's 64 K ----
+        {
+            const uint32_t tag = (epoch << 17) | (sync & 0x1ffffu);
+            unsigned long long* base = g_fps_cbuf +
+                (((size_t)(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + scene) * 2 + (sync & 1)) * FPS_MAX_K * FPS_CC_GRANULES;
+            if (t < FPS_CC_GRANULES)
+                __hip_atomic_store(base + g * FPS_CC_GRANULES + t, ((unsigned long long)tag << 32) | rec[t], __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            const int total = K * FPS_CC_GRANULES;
+            unsigned long long g0 = 0, g1 = 0;
+            bool ok0 = t >= total, ok1 = t + FPS_THREADS >= total;
+            bool failed = false;
+            for (int spin = 0;; ++spin) {
+                if (!ok0) { g0 = __hip_atomic_load(base + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok0 = (uint32_t)(g0 >> 32) == tag; }
+                if (!ok1) { g1 = __hip_atomic_load(base + t + FPS_THREADS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); ok1 = (uint32_t)(g1 >> 32) == tag; }
+                if (__ballot(!ok0 || !ok1) == 0ull) break;
+                if (spin >= spin_limit) { failed = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (t < total) allrec[t] = (uint32_t)g0;
+            if (t + FPS_THREADS < total) allrec[t + FPS_THREADS] = (uint32_t)g1;
+            if (failed && lane == 0) {
+                failflag = 1;
+                __hip_atomic_store(&g_fps_fail[(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + scene], epoch, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+                atomicAdd(&g_fps_fail_total, 1ull);
+            }
+        }
+        lds_barrier();
+        if (failflag) break;       // an exchange timed out: stop (bounded); fps_recover_kernel redoes this scene
+        // ---- the walk: wave 0 of every workgroup, over the same 64 K records (slot q of a lane = row `lane` of workgroup q) ----
+        if (w == 0) {
+            float val[FPS_MAX_K], rx[FPS_MAX_K], ry[FPS_MAX_K], rz[FPS_MAX_K], sec[FPS_MAX_K];
+            uint32_t rT[FPS_MAX_K];
+#pragma unroll
+            for (int q = 0; q < FPS_MAX_K; ++q) {
+                const uint32_t* r = allrec + (q * FPS_RECORDS + lane) * FPS_CC_WORDS;
+                const bool live = q < K;
+                val[q] = live ? __builtin_bit_cast(float, r[0]) : -1.f;
+                rT[q] = live ? r[1] : 0xffffffffu;
+                rx[q] = live ? __builtin_bit_cast(float, r[2]) : 0.f;
+                ry[q] = live ? __builtin_bit_cast(float, r[3]) : 0.f;
+                rz[q] = live ? __builtin_bit_cast(float, r[4]) : 0.f;
+                sec[q] = live ? __builtin_bit_cast(float, r[5]) : -1.f;
+            }
+            int sbound = __builtin_bit_cast(int, -1.f);
+            float lbound = -1.f;
+            int ox = 0, oy = 0, oz = 0, oT = 0;
+            const int rem = min(FPS_CHAIN_MAX, m - j);
+            int c = 0;
+            while (c < rem) {
+                float cv = fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])), mb = lbound;
+                wave_max2_f32(cv, mb);
+                const int cvi = __builtin_bit_cast(int, cv), mbi = __builtin_bit_cast(int, mb);
+                if (cvi < 0 || max(sbound, mbi) >= cvi) break;
+                // my best tie-break value among the slots that hold the maximum, and that slot's record
+                uint32_t lT = 0xffffffffu;
+                float lx = 0.f, ly = 0.f, lz = 0.f, ls = -1.f;
+#pragma unroll
+                for (int q = 0; q < FPS_MAX_K; ++q) {
+                    const bool better = val[q] == cv && rT[q] < lT;
+                    lT = better ? rT[q] : lT; lx = better ? rx[q] : lx; ly = better ? ry[q] : ly; lz = better ? rz[q] : lz; ls = better ? sec[q] : ls;
+                }
+                const uint32_t cT = wave_min_u32(lT);
+                const int wl = (int)__builtin_ctzll(__ballot(lT == cT) | (1ull << 63));
+                const int sxi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, lx), wl);
+                const int syi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, ly), wl);
+                const int szi = __builtin_amdgcn_readlane(__builtin_bit_cast(int, lz), wl);
+                sbound = max(sbound, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ls), wl));
+                const bool mine = lane == c;
+                ox = mine ? sxi : ox; oy = mine ? syi : oy; oz = mine ? szi : oz; oT = mine ? (int)cT : oT;
+                const float sx = __builtin_bit_cast(float, sxi), sy = __builtin_bit_cast(float, syi), sz = __builtin_bit_cast(float, szi);
+#pragma unroll
+                for (int q = 0; q < FPS_MAX_K; ++q) {
+                    if (lane == wl && val[q] == cv && rT[q] == cT) val[q] = -1.f;        // the sample's own record goes first
+                    const float d = sqdist3(rx[q], ry[q], rz[q], sx, sy, sz);
+                    const bool reach = d < val[q];
+                    lbound = reach ? fmaxf(lbound, fmaxf(sec[q], d)) : lbound;
+                    val[q] = reach ? -1.f : val[q];
+                }
+                ++c;
+            }
+            if (lane < c) {
+                chain[lane] = make_float4(__builtin_bit_cast(float, ox), __builtin_bit_cast(float, oy), __builtin_bit_cast(float, oz),
+                                          __builtin_bit_cast(float, oT));
+                if (g == 0) idx[j + lane] = (int)fps_tiebreak_decode((uint32_t)oT, L);
+            }
+            if (lane == 0) chain_n = c;
+        }
+        lds_barrier();
+        cn = __builtin_amdgcn_readfirstlane(chain_n);
+        j += cn;
+        ++sync;
+    }
+#pragma unroll
+    for (int i = 0; i < P; ++i) {
+        const int k = kk_lds[i * FPS_THREADS + t];
+        if (k != 0xffff) temp[k] = tp[i];
+    }
+}
+
 template <bool WITH_DIST>
 __device__ __forceinline__ void fps_stream_scene(const float* __restrict__ data, float* __restrict__ temp,
                                                  int32_t* __restrict__ idx, int n, int m, int L, uint2 (*slots)[FPS_WAVES]) {
@@ -876,8 +1097,14 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
                 const int nb = std::min(chunk, b - s0);
                 uint32_t epoch = epoch_counter.fetch_add(1) & 0x7fffu;
                 if (epoch == 0) epoch = epoch_counter.fetch_add(1) & 0x7fffu;   // 0 = "no failure" in g_fps_fail
-                hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
-                                   data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
+                // several samples per exchange (fps_chain_coop_kernel); PDA_FPS_COOP_CHAIN=0: one winner per round
+                static const bool coop_chain = !(getenv("PDA_FPS_COOP_CHAIN") && atoi(getenv("PDA_FPS_COOP_CHAIN")) == 0);
+                if (coop_chain)
+                    hipLaunchKernelGGL((fps_chain_coop_kernel<16>), dim3(nb * K), block, 0, stream,
+                                       data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
+                else
+                    hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
+                                       data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
                 hipLaunchKernelGGL(fps_recover_kernel, dim3(nb), block, 0, stream, data + (size_t)s0 * n * 3,
                                    temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, epoch);
             }
