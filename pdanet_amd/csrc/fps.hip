@@ -732,6 +732,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
 // second-best value; which workgroup owns the row does not matter); the exchange, its bounded polls and the failure model
 // are fps_pruned_kernel<P, true>'s (a timeout marks the scene, every workgroup stops, fps_recover_kernel recomputes it).
 // Indices and the final temp are bit-identical to the reference.
+#ifndef PDA_FPS_CC_CHAIN_MAX
+#define PDA_FPS_CC_CHAIN_MAX 32
+#endif
+constexpr int FPS_CC_CHAIN_MAX = PDA_FPS_CC_CHAIN_MAX;     // samples per exchange at most (a lane of the walk collects one: <= 64)
 constexpr int FPS_CC_WORDS = 6;                   // value, T, x, y, z, second-best value
 constexpr int FPS_CC_GRANULES = FPS_RECORDS * FPS_CC_WORDS;      // per workgroup and synchronisation
 __device__ unsigned long long g_fps_cbuf[FPS_XBUF_REGIONS * FPS_XBUF_SCENES * 2 * FPS_MAX_K * FPS_CC_GRANULES];
@@ -744,7 +748,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_coop_kernel(const float
     __shared__ uint32_t skey[NS];            // the sort's keys; behind the set-up: the records of all K workgroups
     __shared__ float red[FPS_WAVES * 6];
     __shared__ uint32_t rec[FPS_CC_GRANULES];   // my 64 records, [row][word]
-    __shared__ float4 chain[FPS_CHAIN_MAX];
+    __shared__ float4 chain[FPS_CC_CHAIN_MAX];
     __shared__ int chain_n, failflag;
     const int t = threadIdx.x;
     const int lane = lane_id();
@@ -889,7 +893,7 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_coop_kernel(const float
             int sbound = __builtin_bit_cast(int, -1.f);
             float lbound = -1.f;
             int ox = 0, oy = 0, oz = 0, oT = 0;
-            const int rem = min(FPS_CHAIN_MAX, m - j);
+            const int rem = min(FPS_CC_CHAIN_MAX, m - j);
             int c = 0;
             while (c < rem) {
                 float cv = fmaxf(fmaxf(val[0], val[1]), fmaxf(val[2], val[3])), mb = lbound;
