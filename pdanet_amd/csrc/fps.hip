@@ -1087,8 +1087,9 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
         return check_launch(what);
     }
     static const int no_coop = getenv("PDA_FPS_NO_COOP") ? atoi(getenv("PDA_FPS_NO_COOP")) : 0;
-    // (16384, 24576] stays on the single-workgroup register kernel: 6.3 ms vs 7.7-9.0 ms cooperative
-    if (!no_prune && !no_coop && n > 24 * FPS_THREADS && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
+    // every n above one workgroup's 16384 points (the register kernel held 16385...24576: 9.3 ms against 5.3 at 24576 -> 6144)
+    static const int coop_from = getenv("PDA_FPS_COOP_FROM") ? atoi(getenv("PDA_FPS_COOP_FROM")) : 16384;
+    if (!no_prune && !no_coop && n > coop_from && n > 16384 && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
         // K workgroups per scene, all resident together: a launch holds at most what the device admits at once
         // (one 1024-lane workgroup per CU for this kernel; the occupancy query only confirms >= 1) and 64 scenes
         static std::atomic<uint32_t> epoch_counter{1};

@@ -59,8 +59,9 @@ def fps_both(ext, oracle, xyz, m):
     (2, 1024, 1024, "U"),      # m == n
     (1, 1500, 7, "L"),         # n not a power of two, P = 2 with empty slots
     (2, 5000, 512, "L"),       # P = 8 (5 slots used)
-    (1, 20000, 256, "L"),      # P = 24 register kernel
-    (1, 30000, 128, "L"),      # streaming kernel (n > 24576)
+    (1, 20000, 256, "L"),      # 16384 < n <= 65536: the cooperative chain kernel (K = 2)
+    (1, 30000, 128, "L"),      # the same, K = 2
+    (1, 70000, 300, "L"),      # streaming kernel (n > 65536)
     (1, 65, 65, "U"), (1, 64, 10, "U"), (1, 3, 3, "U"), (1, 1, 1, "U"),
 ])
 def test_fps_index_exact(ext, oracle, b, n, m, dist):
@@ -106,6 +107,41 @@ def test_fps_chain_kernel_edge_cases(ext, oracle, case):
     idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
     assert np.array_equal(idx_o, idx_d)
     assert np.array_equal(temp_o, temp_d)
+
+
+@pytest.mark.parametrize("case", ["k2_full", "k2_small_tail", "k4_long", "duplicates", "lattice", "two_clusters", "line", "select_many"])
+def test_fps_cooperative_chain_kernel_cases(ext, oracle, case):
+    """fps_chain_coop_kernel (16384 < n <= 65536: K = 2...4 workgroups per scene, each publishing its 64 row records, every
+    workgroup walking the scene's 64 K): whole runs at K = 2 and K = 4 (ragged last workgroup), and the cases where the walk's
+    proofs are tight ACROSS workgroups -- duplicated points owned by different workgroups, dense lattices (equal values in
+    records of different workgroups: the tie-break value decides), two far clusters, collinear points, a large share of the
+    cloud selected."""
+    rng = np.random.default_rng(23)
+    if case == "k2_full":
+        xyz, m = cloud(2, 24576, seed=5), 6144
+    elif case == "k2_small_tail":
+        xyz, m = cloud(2, 16385, seed=6), 4096                      # the second workgroup owns 8192 points, one more than... a ragged split
+    elif case == "k4_long":
+        xyz, m = cloud(1, 50000, seed=7), 12500
+    elif case == "duplicates":
+        base = rng.normal(size=(1, 2000, 3)).astype(np.float32)
+        xyz, m = np.ascontiguousarray(np.tile(base, (1, 10, 1))[:, rng.permutation(20000)]), 5000    # every point ten times, K = 2
+    elif case == "lattice":
+        xyz, m = rng.integers(0, 14, size=(1, 40000, 3)).astype(np.float32), 4000                    # 2744 distinct sites, K = 3
+    elif case == "two_clusters":
+        xyz = rng.normal(size=(1, 30000, 3)).astype(np.float32)
+        xyz[0, ::2] += np.float32(1000.0)
+        m = 6000
+    elif case == "line":
+        xyz = np.zeros((1, 20000, 3), np.float32); xyz[0, :, 0] = rng.permutation(20000).astype(np.float32) * 0.25
+        m = 5000
+    else:
+        xyz, m = cloud(1, 17000, seed=8), 16000
+    ext.fps_coop_timeouts(reset=True)
+    idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+    assert np.array_equal(idx_o, idx_d)
+    assert np.array_equal(temp_o, temp_d)
+    assert ext.fps_coop_timeouts() == 0
 
 
 def test_fps_known_answers_on_gpu(ext):
