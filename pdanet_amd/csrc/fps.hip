@@ -21,8 +21,9 @@
 //   points per v_pk_{add,mul,fma}_f32 is 13 % SLOWER (5.40 vs 4.79 ms: packed f32 issues at half
 //   rate and costs extra moves), 512 lanes x 32 points/lane 22-36 % slower (fewer waves to
 //   cover the reduction latency).
-// fps_pruned_kernel<P,COOP> (2048 <= N <= 16384 single workgroup; 24576 < N <= 65536 cooperative:
-//   K = ceil(N/16384) workgroups per scene, see the comment at the kernel)
+// fps_chain_kernel<P> (2048 <= N <= 16384: several samples per synchronisation, see the comment at the kernel)
+// fps_chain_coop_kernel<16> (16384 < N <= 65536: K = ceil(N/16384) workgroups per scene, several samples per exchange)
+// fps_pruned_kernel<P,COOP> (their one-sample-per-round forms: PDA_FPS_NO_CHAIN=1 / PDA_FPS_COOP_CHAIN=0)
 // fps_stream_kernel<WITH_DIST> (any other N; also the (B,N,N) distance-matrix variant)
 //   * same reduction, but xyz (or the dist row) and temp stream from L2/HBM each iteration.
 // Algorithmic bytes: (m-1)*N*20 + m*4 per scene; compulsory bytes N*16 + m*4.
@@ -731,7 +732,10 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_chain_kernel(const float* __r
 // acceptance rule and its proof are fps_chain_kernel's (a record = any set of points with its best point, best value and
 // second-best value; which workgroup owns the row does not matter); the exchange, its bounded polls and the failure model
 // are fps_pruned_kernel<P, true>'s (a timeout marks the scene, every workgroup stops, fps_recover_kernel recomputes it).
-// Indices and the final temp are bit-identical to the reference.
+// Indices and the final temp are bit-identical to the reference.  Measured: 60000 -> 16384, 2 scenes 34.5 -> 12.5 ms.  Dead ends:
+// the K workgroups of a scene placed on ONE XCD (blockIdx = 8 (K j + g) + s): 12.43 against 12.58 ms -- the agent-scope granules
+// travel through memory either way; K = 2 / 4 workgroups on 16384 points (PDA_FPS_COOP_KMIN): 3.8-3.9 ms against
+// fps_chain_kernel's 2.40 -- an exchange costs more than the smaller shares save.
 #ifndef PDA_FPS_CC_CHAIN_MAX
 #define PDA_FPS_CC_CHAIN_MAX 32
 #endif
@@ -1072,14 +1076,15 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
     const int P = divup(n, FPS_THREADS);
     static const int no_prune = getenv("PDA_FPS_NO_PRUNE") ? atoi(getenv("PDA_FPS_NO_PRUNE")) : 0;
     static const int no_chain = getenv("PDA_FPS_NO_CHAIN") ? atoi(getenv("PDA_FPS_NO_CHAIN")) : 0;
-    if (!no_prune && !no_chain && n >= 2048 && n <= 16384 && m > 2) {
+    static const int coop_kmin = getenv("PDA_FPS_COOP_KMIN") ? atoi(getenv("PDA_FPS_COOP_KMIN")) : 1;     // experiments: more workgroups per scene
+    if (!no_prune && !no_chain && n >= 2048 && n <= 16384 && m > 2 && coop_kmin <= 1) {
         if (P <= 2) hipLaunchKernelGGL((fps_chain_kernel<2>), grid, block, 0, stream, data, temp, idx, n, m, L);
         else if (P <= 4) hipLaunchKernelGGL((fps_chain_kernel<4>), grid, block, 0, stream, data, temp, idx, n, m, L);
         else if (P <= 8) hipLaunchKernelGGL((fps_chain_kernel<8>), grid, block, 0, stream, data, temp, idx, n, m, L);
         else hipLaunchKernelGGL((fps_chain_kernel<16>), grid, block, 0, stream, data, temp, idx, n, m, L);
         return check_launch(what);
     }
-    if (!no_prune && n >= 2048 && n <= 16384 && m > 2) {
+    if (!no_prune && n >= 2048 && n <= 16384 && m > 2 && coop_kmin <= 1) {
         if (P <= 2) hipLaunchKernelGGL((fps_pruned_kernel<2, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
         else if (P <= 4) hipLaunchKernelGGL((fps_pruned_kernel<4, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
         else if (P <= 8) hipLaunchKernelGGL((fps_pruned_kernel<8, false>), grid, block, 0, stream, data, temp, idx, n, m, L, 1, b, 0u);
@@ -1089,13 +1094,13 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
     static const int no_coop = getenv("PDA_FPS_NO_COOP") ? atoi(getenv("PDA_FPS_NO_COOP")) : 0;
     // every n above one workgroup's 16384 points (the register kernel held 16385...24576: 9.3 ms against 5.3 at 24576 -> 6144)
     static const int coop_from = getenv("PDA_FPS_COOP_FROM") ? atoi(getenv("PDA_FPS_COOP_FROM")) : 16384;
-    if (!no_prune && !no_coop && n > coop_from && n > 16384 && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
+    if (!no_prune && !no_coop && n > coop_from && (n > 16384 || coop_kmin > 1) && n <= 16384 * FPS_MAX_K && m > 2 && m < (1 << 17)) {
         // K workgroups per scene, all resident together: a launch holds at most what the device admits at once
         // (one 1024-lane workgroup per CU for this kernel; the occupancy query only confirms >= 1) and 64 scenes
         static std::atomic<uint32_t> epoch_counter{1};
         static PerDevice<int> resident_of;
         const int resident = resident_of.get(coop_resident_workgroups);
-        const int K = divup(n, 16384);
+        const int K = std::min(FPS_MAX_K, std::max(divup(n, 16384), coop_kmin));
         const int chunk = std::min(FPS_XBUF_SCENES, resident / K);
         if (chunk >= 1) {
             for (int s0 = 0; s0 < b; s0 += chunk) {

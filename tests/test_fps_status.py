@@ -1,4 +1,4 @@
-"""-m gpu: the multi-workgroup FPS form (24576 < n <= 65536, csrc/fps.hip fps_pruned_kernel<16, true>) can no longer
+"""-m gpu: the multi-workgroup FPS form (16384 < n <= 65536, csrc/fps.hip fps_chain_coop_kernel<16>) can no longer
 fail silently: a timed-out winner exchange is counted, reported through the C ABI
 (pda_fps_coop_timeouts) and the scene is recomputed on the device, so indices and `temp` stay the exact result."""
 import numpy as np
