@@ -157,7 +157,8 @@ class KernelTimers:
                 "note": "achieved = algorithmic bytes ((m-1)*N*20+m*4 per scene: the specified algorithm with no "
                         "on-chip reuse) / kernel time.  The kernel keeps the scene on chip (exact spatial pruning "
                         "skips no-op updates), so its real HBM traffic is the compulsory N*16+m*4 bytes per scene "
-                        "and it is bound by the latency of the dependent arg-max rounds (fps_chain_kernel: ~3.5 samples per synchronisation), not by HBM.  traffic = "
+                        "and it is bound by the latency of the dependent arg-max rounds (fps_chain_kernel: 6.65 samples per synchronisation on the bench scene; "
+                        "fps_chain_coop_kernel, N > 16384: ~12 per exchange between the K workgroups of a scene), not by HBM.  traffic = "
                         "(2*FETCH_SIZE+WRITE_SIZE) KB per launch from the committed rocprofv3 --pmc passes "
                         "(null when the kernel source changed since the pass)"})
         return out
