@@ -49,8 +49,8 @@ int pda_fp_contract_mode(void);
 /* Block size the reference launcher would choose for `work_size` (cuda_utils.h:10-14);
  * it fixes the FPS tie-breaking and is exported so hosts/tests can state it. */
 int pda_opt_n_threads(int work_size);
-/* Diagnostics of the multi-workgroup FPS form (24576 < n <= 65536: K workgroups per scene exchange their
- * round winners through device memory with BOUNDED polls).  A timed-out exchange is recovered on the device
+/* Diagnostics of the multi-workgroup FPS form (16384 < n <= 65536: K workgroups per scene exchange their
+ * row records / round winners through device memory with BOUNDED polls).  A timed-out exchange is recovered on the device
  * (the scene is recomputed by a follow-up kernel on the same stream: results stay exact) and counted;
  * *total = workgroups that timed out since load (or the last reset).  Synchronises the device.
  * The reference has no counterpart: its kernel is one block per scene (sampling_gpu.cu:211-253). */
@@ -58,6 +58,9 @@ int pda_fps_coop_timeouts(unsigned long long *total, int reset);
 /* Test hook: polls per exchange before a workgroup gives up (0 forces the recovery path whenever a partner
  * is late; negative restores the default 1 << 20).  Synchronises the device. */
 int pda_debug_fps_spin_limit(int polls);
+/* Test hook: the number of non-zero exchange granules once everything queued has run (synchronises the device).  The
+ * follow-up kernel of every multi-workgroup launch wipes the granules of its scenes, so this is 0 between launches. */
+long long pda_debug_fps_exchange_nonzero(void);
 
 /* ---- furthest point sampling ------------------------------------------------------- */
 /* replaces farthest_point_sampling_wrapper (sampling.cpp:34-43, pointnet2_api.cpp:27;

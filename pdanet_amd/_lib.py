@@ -141,7 +141,7 @@ SIGNATURES = {
     "pda_stack_three_interpolate_grad": [_vp, _vp, _vp, _vp, _i, _i, _vp],
 }
 INFO_SYMBOLS = ["pda_abi_version", "pda_last_error", "pda_fp_contract_mode", "pda_opt_n_threads",
-                "pda_fps_coop_timeouts", "pda_debug_fps_spin_limit"]
+                "pda_fps_coop_timeouts", "pda_debug_fps_spin_limit", "pda_debug_fps_exchange_nonzero"]
 
 _LIB = None
 
@@ -185,6 +185,8 @@ def load():
     lib.pda_fps_coop_timeouts.restype = _i
     lib.pda_debug_fps_spin_limit.argtypes = [_i]
     lib.pda_debug_fps_spin_limit.restype = _i
+    lib.pda_debug_fps_exchange_nonzero.argtypes = []
+    lib.pda_debug_fps_exchange_nonzero.restype = ctypes.c_longlong
     if lib.pda_abi_version() != ABI_VERSION:
         raise PdaError("libpda_pointnet2.so ABI %d != binding ABI %d: rebuild"
                        % (lib.pda_abi_version(), ABI_VERSION))

@@ -993,11 +993,20 @@ __global__ __launch_bounds__(FPS_THREADS) void fps_stream_kernel(const float* __
 
 // Behind every cooperative launch, same stream, one workgroup per scene: returns at once unless an exchange of
 // that launch timed out for its scene; then it recomputes the scene from scratch with the streaming algorithm.
+// It also wipes the exchange granules the launch used for its scene (`xbuf`: `xcount` granules per scene of this region):
+// every workgroup of the cooperative launch has finished by now, so no reader can miss a record, and no granule keeps a
+// tag that a launch 32767 epochs later -- same 15-bit epoch, same region, same round numbers -- would take for its own.
 __global__ __launch_bounds__(FPS_THREADS) void fps_recover_kernel(const float* __restrict__ xyz_all,
                                                                    float* __restrict__ temp_all,
                                                                    int32_t* __restrict__ idx_all, int n, int m,
-                                                                   int L, uint32_t epoch) {
+                                                                   int L, uint32_t epoch, unsigned long long* __restrict__ xbuf,
+                                                                   int xcount) {
     __shared__ uint2 slots[2][FPS_WAVES];
+    {
+        unsigned long long* mine = xbuf + ((size_t)(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + blockIdx.x) * xcount;
+        for (int i = threadIdx.x; i < xcount; i += FPS_THREADS)
+            __hip_atomic_store(mine + i, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     unsigned int* mark = &g_fps_fail[(epoch % FPS_XBUF_REGIONS) * FPS_XBUF_SCENES + blockIdx.x];
     if (__hip_atomic_load(mark, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != epoch) return;   // wave-uniform
     float* __restrict__ temp = temp_all + (size_t)blockIdx.x * n;
@@ -1115,8 +1124,14 @@ static int launch_fps(bool with_dist, const float* data, float* temp, int32_t* i
                 else
                     hipLaunchKernelGGL((fps_pruned_kernel<16, true>), dim3(nb * K), block, 0, stream,
                                        data + (size_t)s0 * n * 3, temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, K, nb, epoch);
+                static PerDevice<unsigned long long*> cbuf_of, xbuf_of;
+                unsigned long long* xbuf = coop_chain
+                    ? cbuf_of.get([] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(g_fps_cbuf)) == hipSuccess ? (unsigned long long*)q : (unsigned long long*)nullptr; })
+                    : xbuf_of.get([] { void* q = nullptr; return hipGetSymbolAddress(&q, HIP_SYMBOL(g_fps_xbuf)) == hipSuccess ? (unsigned long long*)q : (unsigned long long*)nullptr; });
+                const int xcount = 2 * FPS_MAX_K * (coop_chain ? FPS_CC_GRANULES : 5);      // both parities, all K slots
+                PDA_REQUIRE(xbuf != nullptr, "%s: exchange buffer symbol", what);
                 hipLaunchKernelGGL(fps_recover_kernel, dim3(nb), block, 0, stream, data + (size_t)s0 * n * 3,
-                                   temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, epoch);
+                                   temp + (size_t)s0 * n, idx + (size_t)s0 * m, n, m, L, epoch, xbuf, xcount);
             }
             return check_launch(what);
         }   // a device too small to hold the K workgroups of one scene: streaming kernel below
@@ -1159,6 +1174,18 @@ PDA_API int pda_fps_coop_timeouts(unsigned long long* total, int reset) {
         }
     }
     return PDA_OK;
+}
+
+// number of non-zero exchange granules (both buffers) after everything queued has run: 0 when every launch was wiped
+PDA_API long long pda_debug_fps_exchange_nonzero(void) {
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    static unsigned long long host[sizeof(pda::g_fps_cbuf) / sizeof(unsigned long long)];
+    long long count = 0;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pda::g_fps_cbuf), sizeof(pda::g_fps_cbuf)) != hipSuccess) return -1;
+    for (size_t i = 0; i < sizeof(pda::g_fps_cbuf) / sizeof(unsigned long long); ++i) count += host[i] != 0;
+    if (hipMemcpyFromSymbol(host, HIP_SYMBOL(pda::g_fps_xbuf), sizeof(pda::g_fps_xbuf)) != hipSuccess) return -1;
+    for (size_t i = 0; i < sizeof(pda::g_fps_xbuf) / sizeof(unsigned long long); ++i) count += host[i] != 0;
+    return count;
 }
 
 PDA_API int pda_debug_fps_spin_limit(int polls) {

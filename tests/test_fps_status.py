@@ -58,3 +58,19 @@ def test_cooperative_fps_on_the_side_stream_gives_the_same_backbone_output(monke
     assert ext.fps_coop_timeouts() == 0
     for a, b in zip(outs["0"], outs["1"]):
         assert torch.equal(a, b)
+
+
+def test_exchange_granules_are_wiped_behind_every_launch(ext, oracle):
+    """The tag of an exchange granule is (15-bit launch epoch, round): a launch 32767 epochs later would read a leftover
+    granule of the same scene, region and round as its own.  fps_recover_kernel, which runs behind every cooperative
+    launch, wipes the granules of its scene; so the state after a launch is the state before the first one, and repeated
+    launches (here more than the four regions the epochs rotate through) keep giving the exact result."""
+    b, n, m = 2, 30000, 300
+    xyz = cloud(b, n, seed=91)
+    ext.fps_coop_timeouts(reset=True)
+    for _ in range(9):
+        idx_o, temp_o, idx_d, temp_d = fps_both(ext, oracle, xyz, m)
+        assert np.array_equal(idx_o, idx_d) and np.array_equal(temp_o, temp_d)
+    assert ext.fps_coop_timeouts() == 0
+    from pdanet_amd import _lib
+    assert _lib.load().pda_debug_fps_exchange_nonzero() == 0
