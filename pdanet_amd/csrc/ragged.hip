@@ -22,24 +22,28 @@
 
 namespace pda {
 
-// One workgroup.  Thread t owns the `per` consecutive groups starting at t * per: counts their distinct entries
-// (1 + number of entries that differ from the first: real hits are distinct and ascending, padding repeats entry 0),
-// then an exclusive scan over all groups.  off has groups + 1 entries; off[groups] = U.
-__global__ __launch_bounds__(1024) void ragged_plan_kernel(const int32_t* __restrict__ idx, int32_t* __restrict__ cnt,
-                                                           int32_t* __restrict__ off, int groups, int ns) {
+// cnt[g] = the distinct entries of group g (1 + number of entries that differ from the first: real hits are distinct and
+// ascending, padding repeats entry 0).  One thread per group over the whole grid (a single workgroup walking 32 768 lists of
+// config 5 took 250 us in front of the layer's host read).
+__global__ __launch_bounds__(256) void ragged_count_kernel(const int32_t* __restrict__ idx, int32_t* __restrict__ cnt, int groups, int ns) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const int32_t* row = idx + (size_t)g * ns;
+    const int32_t first = row[0];
+    int32_t c = 1;
+    for (int s = 1; s < ns; ++s) c += row[s] != first ? 1 : 0;
+    cnt[g] = c;
+}
+
+// One workgroup: exclusive scan of cnt over all groups.  Thread t owns the `per` consecutive groups starting at t * per.
+// off has groups + 1 entries; off[groups] = U.
+__global__ __launch_bounds__(1024) void ragged_plan_kernel(const int32_t* __restrict__ cnt, int32_t* __restrict__ off, int groups) {
     __shared__ int32_t part[1024];
     const int t = threadIdx.x;
     const int per = (groups + 1023) / 1024;
     const int g0 = t * per, g1 = min(groups, g0 + per);
     int32_t sum = 0;
-    for (int g = g0; g < g1; ++g) {
-        const int32_t* row = idx + (size_t)g * ns;
-        const int32_t first = row[0];
-        int32_t c = 1;
-        for (int s = 1; s < ns; ++s) c += row[s] != first ? 1 : 0;
-        cnt[g] = c;
-        sum += c;
-    }
+    for (int g = g0; g < g1; ++g) sum += cnt[g];
     part[t] = sum;
     __syncthreads();
     for (int o = 1; o < 1024; o <<= 1) {        // Hillis-Steele inclusive scan of the 1024 partial sums
@@ -197,7 +201,10 @@ PDA_API int pda_ragged_plan(const int32_t* idx, int32_t* cnt, int32_t* off, int3
                 "pda_ragged_plan: groups=%lld nsample=%d", (long long)groups, nsample);
     PDA_REQUIRE(off != nullptr, "pda_ragged_plan: null pointer");
     PDA_REQUIRE(groups == 0 || (idx && cnt && rowmap), "pda_ragged_plan: null pointer");
-    hipLaunchKernelGGL(pda::ragged_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, idx, cnt, off, (int)groups, nsample);
+    if (groups > 0)
+        hipLaunchKernelGGL(pda::ragged_count_kernel, dim3((unsigned)pda::divup64(groups, 256)), dim3(256), 0, (hipStream_t)stream, idx, cnt,
+                           (int)groups, nsample);
+    hipLaunchKernelGGL(pda::ragged_plan_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, cnt, off, (int)groups);
     if (groups > 0) {
         const int64_t total = groups * nsample;
         hipLaunchKernelGGL(pda::ragged_rowmap_kernel, dim3((unsigned)pda::divup64(total, 256)), dim3(256), 0, (hipStream_t)stream, cnt,
