@@ -122,7 +122,7 @@ def test_fps_cooperative_chain_kernel_cases(ext, oracle, case):
     elif case == "k2_small_tail":
         xyz, m = cloud(2, 16385, seed=6), 4096                      # the second workgroup owns 8192 points, one more than... a ragged split
     elif case == "k4_long":
-        xyz, m = cloud(1, 50000, seed=7), 12500
+        xyz, m = cloud(1, 50000, seed=7), 8000
     elif case == "duplicates":
         base = rng.normal(size=(1, 2000, 3)).astype(np.float32)
         xyz, m = np.ascontiguousarray(np.tile(base, (1, 10, 1))[:, rng.permutation(20000)]), 5000    # every point ten times, K = 2
