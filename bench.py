@@ -125,6 +125,33 @@ def step_text(name):
     return name
 
 
+def pin_to_gpu_node(torch, device_index):
+    """Keep this rank's threads on the CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` does for a launcher;
+    the driver starts `python bench.py` bare).  A host-bound iteration is 10-15 % slower when the launching thread sits on the
+    other socket, and the scheduler moves it between the two from run to run (KITTI, B = 4: 12.3-12.8 against 14.1-14.5 ms per
+    step, build/kitti_dist.py).  PDA_PIN_CPUS=0 leaves the affinity alone.  Returns a description for the result line."""
+    if os.environ.get("PDA_PIN_CPUS", "1") == "0":
+        return "unchanged (PDA_PIN_CPUS=0)"
+    try:
+        p = torch.cuda.get_device_properties(device_index)
+        bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+        cpus = set()
+        for part in open("/sys/bus/pci/devices/%s/local_cpulist" % bdf).read().strip().split(","):
+            lo, _, hi = part.partition("-")
+            cpus.update(range(int(lo), int(hi or lo) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if not cpus:
+            return "unchanged (no local CPU in the allowed set)"
+        for tid in os.listdir("/proc/self/task"):          # the threads torch has started already; later ones inherit
+            try:
+                os.sched_setaffinity(int(tid), cpus)
+            except OSError:
+                pass
+        return "GPU-local NUMA node of %s: %d CPUs" % (bdf, len(cpus))
+    except Exception as e:  # noqa: BLE001  (an unreadable sysfs must not cost the run)
+        return "unchanged (%r)" % (e,)
+
+
 def main():
     argv = sys.argv[1:]
     args = parse_args(argv)
@@ -159,6 +186,7 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    cpu_affinity = pin_to_gpu_node(torch, local_rank)
     parallel.init_distributed("nccl", device)  # backend "nccl" is RCCL on ROCm; no-op for 1 GPU
     seen_world = dist.get_world_size() if dist.is_initialized() else 1
     assert seen_world == args.gpus, (seen_world, args.gpus)
@@ -196,6 +224,7 @@ def main():
     if hasattr(wl, "tuned"):
         line["config"]["hipblaslt_tunableop_results_loaded"] = bool(wl.tuned)
     line["config"]["peak_mem_GiB"] = round(torch.cuda.max_memory_allocated(device) / 2**30, 2)
+    line["config"]["cpu_affinity"] = cpu_affinity
     if hasattr(getattr(wl, "model", None), "graph_tail"):
         # layers 3-5 + head + losses replayed as hipGraphs: chosen by the workload when the host was the limit (workloads.py)
         line["config"]["graph_tail"] = bool(wl.model.graph_tail)
