@@ -432,7 +432,7 @@ class BackboneWorkload(KernelTimers):
         self._prefetch_next()
         loss = self.loss_of(bd)
         loss.backward()
-        return loss
+        return loss.detach()
 
     def _prefetch_next(self):
         """The next iteration's batch is resident already (synthetic data; a data loader's prefetch in a real run): start its
@@ -636,7 +636,7 @@ class TrainStepWorkload(BackboneWorkload):
         loss.backward()
         self.opt.step()
         self.it += 1
-        return loss
+        return loss.detach()
 
 
 class DetectorTrainWorkload(TrainStepWorkload):
@@ -750,7 +750,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         ret['loss'].backward()
         self.opt.step()
         self.it += 1
-        self.tb = tb
+        self.tb = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in tb.items()}
         if probe:
             t1 = time.perf_counter()
             torch.cuda.synchronize()
@@ -758,7 +758,11 @@ class DetectorTrainWorkload(TrainStepWorkload):
             self.host_bound = (t1 - t0) > 0.93 * (t2 - t0)      # the GPU was done (almost) as soon as the host was
             self.model.graph_tail = self.host_bound
             self._tail_auto = False
-        return ret['loss']
+        # DETACHED: a caller that keeps the returned loss (`loss = wl.step()` in a loop) must not keep the iteration's autograd
+        # graph alive with it.  With the graph of an earlier iteration alive, the capture of the tail graph on the next
+        # iteration (graph_tail chosen by the probe above) dies inside hipStreamEndCapture (ROCm 7.2; torch/cuda/graphs.py
+        # capture_end; reproduced with build/soak4.py MODE=keep, gone with the reference dropped).
+        return ret['loss'].detach()
 
 
 def create(name, batch, n_points, device, rank, world):

@@ -104,6 +104,9 @@ class IASSD(nn.Module):
         self.graph_head = False
         # graph_tail: the same from the first backbone layer behind the last unique-token plan (backbone.
         # first_static_tail_layer: ONCE layers 3, 4, 5) -- everything after the step's last host read is two replays.
+        # Switch either flag on BEFORE the first backward pass, or with nothing an earlier iteration returned still alive: a
+        # capture next to a live autograd graph that references the captured parameters dies inside hipStreamEndCapture
+        # (ROCm 7.2; DESIGN.md "Known gaps").
         self.graph_tail = False
         self._graphed = None
         self._graphed_tail = None
