@@ -396,6 +396,18 @@ def layer_norm_bwd(x, grad_y, gamma, mean_rstd, grad_x, grad_gamma, grad_beta, s
 _WGRAD_SCRATCH_BYTES = {}
 
 
+def _wgrad_scratch_bytes(tokens, in_features, out_features):
+    # ~60 weight gradients per training step: the size query is a foreign call of its own, so it is cached -- boundedly: the
+    # token counts of the unique-token encoder change every step, and a table keyed on them would grow for as long as a run lasts
+    key = (tokens, in_features, out_features)
+    nbytes = _WGRAD_SCRATCH_BYTES.get(key)
+    if nbytes is None:
+        if len(_WGRAD_SCRATCH_BYTES) >= 4096:
+            _WGRAD_SCRATCH_BYTES.clear()
+        nbytes = _WGRAD_SCRATCH_BYTES[key] = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    return nbytes
+
+
 @functools.lru_cache(maxsize=None)
 def _split_packed_bytes(n_out, k):
     """Size queries are pure functions of the shape: cached, a training step asks ~300 times (each a foreign call)."""
@@ -411,10 +423,7 @@ def linear_wgrad(x, grad_out, grad_weight, grad_bias, tokens, in_features, out_f
     """MI355X extension: grad_weight (out, in) = grad_out^T x and grad_bias = column sums (csrc/wgrad.hip)."""
     _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
     _numel_ok(grad_weight, in_features * out_features, "grad_weight")
-    key = (tokens, in_features, out_features)
-    nbytes = _WGRAD_SCRATCH_BYTES.get(key)
-    if nbytes is None:      # ~60 weight gradients per training step: the size query is a foreign call of its own
-        nbytes = _WGRAD_SCRATCH_BYTES[key] = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    nbytes = _wgrad_scratch_bytes(tokens, in_features, out_features)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     gb = None if grad_bias is None else _chk(grad_bias, "grad_bias", F32)
     _call("pda_linear_wgrad", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32),
@@ -428,10 +437,7 @@ def linear_wgrad_bn(x, grad_out, grad_weight, tokens, in_features, out_features,
     _numel_ok(x, tokens * in_features, "x"); _numel_ok(grad_out, tokens * out_features, "grad_out")
     _numel_ok(grad_weight, in_features * out_features, "grad_weight"); _numel_ok(x_mean_invstd, 2 * in_features, "x_mean_invstd")
     _numel_ok(x_gamma, in_features, "x_gamma"); _numel_ok(x_beta, in_features, "x_beta")
-    key = (tokens, in_features, out_features)
-    nbytes = _WGRAD_SCRATCH_BYTES.get(key)
-    if nbytes is None:
-        nbytes = _WGRAD_SCRATCH_BYTES[key] = int(_lib.load().pda_linear_wgrad_scratch_bytes(tokens, in_features, out_features))
+    nbytes = _wgrad_scratch_bytes(tokens, in_features, out_features)
     scratch = torch.empty((nbytes,), dtype=torch.uint8, device=x.device)
     _call("pda_linear_wgrad_bn", x, _chk(x, "x", F32), _chk(grad_out, "grad_out", F32), _chk(grad_weight, "grad_weight", F32), None,
           _chk(scratch, "scratch", torch.uint8), tokens, in_features, out_features, _chk(x_mean_invstd, "x_mean_invstd", F32),
