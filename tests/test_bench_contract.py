@@ -96,3 +96,24 @@ def test_two_ranks_reference_shaped_ddp_path():
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 2 and "DistributedDataParallel" in d["config"]["gradient_exchange"]
     assert d["config"]["graph_head"] is False and d["config"]["graph_tail"] is False
+
+
+@pytest.mark.gpu
+def test_a_training_loop_that_keeps_its_loss_survives_the_late_tail_capture():
+    """`loss = wl.step()` in a loop keeps the previous iteration's return value alive while the next one runs.  The KITTI
+    workload captures its tail graph on the fifth iteration (the host-bound probe runs on the fourth); with the autograd graph
+    of the fourth iteration alive through that loss, the capture died inside hipStreamEndCapture (DESIGN.md "Known gaps").
+    The workloads return the loss detached: the loop below -- in its own process, a crash there is a signal, not an
+    exception -- must come through, with the tail graphed."""
+    code = ("import sys, torch; sys.path.insert(0, %r)\n"
+            "from benchmarks import workloads as bw\n"
+            "wl = bw.create('kitti_detector_train', 4, 16384, torch.device('cuda:0'), 0, 1); wl.begin()\n"
+            "for i in range(8):\n"
+            "    l = wl.step()\n"
+            "torch.cuda.synchronize()\n"
+            "assert not l.requires_grad and l.grad_fn is None\n"
+            "print('graph_tail', wl.model.graph_tail, float(l))\n" % ROOT)
+    env = dict(os.environ, PDA_GRAPH_TAIL="auto", PYTHONFAULTHANDLER="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stderr[-3000:])
+    assert "graph_tail" in r.stdout
