@@ -132,6 +132,8 @@ def pin_to_gpu_node(torch, device_index):
     step, build/kitti_dist.py).  PDA_PIN_CPUS=0 leaves the affinity alone.  Returns a description for the result line."""
     if os.environ.get("PDA_PIN_CPUS", "1") == "0":
         return "unchanged (PDA_PIN_CPUS=0)"
+    global ALL_CPUS
+    ALL_CPUS = os.sched_getaffinity(0)
     try:
         p = torch.cuda.get_device_properties(device_index)
         bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
@@ -150,6 +152,20 @@ def pin_to_gpu_node(torch, device_index):
         return "GPU-local NUMA node of %s: %d CPUs" % (bdf, len(cpus))
     except Exception as e:  # noqa: BLE001  (an unreadable sysfs must not cost the run)
         return "unchanged (%r)" % (e,)
+
+
+ALL_CPUS = None
+
+
+def unpin():
+    """The CPU baselines use every core of the box (OpenMP in the oracle, torch's intra-op pool): give the threads the whole
+    machine back for them (pinned to one socket, 256 OpenMP threads on 128 CPUs took 4 x as long)."""
+    if ALL_CPUS:
+        for tid in os.listdir("/proc/self/task"):
+            try:
+                os.sched_setaffinity(int(tid), ALL_CPUS)
+            except OSError:
+                pass
 
 
 def main():
@@ -236,6 +252,7 @@ def main():
 
     single = world == 1 and rank == 0
     if single and not args.no_cpu_baseline:
+        unpin()          # (the timed GPU part of this workload is over; the extra workloads below pin again)
         line["cpu_baseline"] = safe(wl.cpu_baseline, {"value": None, "unit": "scenes/s", "cores": None, "kind": "port", "sample": "failed"})
         # the operator baseline "at 1 thread and at all cores"
         xyz_np = getattr(wl, "xyz_np", None)
@@ -245,6 +262,7 @@ def main():
                                     "threads_all": safe(workloads.sampling_grouping_cpu, {}, xyz_np, None)}
 
     if single and not args.no_extra and args.workload == "auto":
+        pin_to_gpu_node(torch, local_rank)
         # secondary timings (few steps each): round 1's headline and BASELINE configs[1] / configs[2]
         del wl
         extra = {}
