@@ -39,7 +39,7 @@ extern "C" {
 typedef void *pda_stream_t; /* hipStream_t */
 
 /* ABI version of this header (bumped on any signature change). */
-#define PDA_POINTNET2_ABI_VERSION 19
+#define PDA_POINTNET2_ABI_VERSION 20
 int pda_abi_version(void);
 /* Message of the last non-PDA_OK status returned on the calling thread ("" if none). */
 const char *pda_last_error(void);

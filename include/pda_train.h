@@ -202,7 +202,9 @@ int pda_bn_relu_bwd_weighted(const float *x, const float *grad_y, const float *g
  *   grad_dscale (zero at the repeat slots) and grad_glob, and ADDS into grad_feats (zero-filled by the caller).
  * pda_add_max_pool_ragged / pda_max_pool_scatter_ragged: the add + max-pool tail on compact rows; arg = slot.
  * pda_group_attention_ragged_fwd/bwd (include/pda_pointnet2.h layout with compact rows): qkv (U, 3, H, hd),
- *   out / grad_out (U, H * hd), lse (groups, H, seq). */
+ *   out / grad_out (U, H * hd), lse (groups, H, seq).  tokens = U (the caller has read it to size qkv): one wave
+ *   packs the distinct tokens of several consecutive groups into 32-row tiles, and U / groups decides how many
+ *   groups a wave takes (a wrong value costs speed, never results). */
 int pda_ragged_plan(const int32_t *idx, int32_t *cnt, int32_t *off, int32_t *rowmap, float *row_weight, int64_t groups,
                     int nsample, pda_stream_t stream);
 int pda_assemble_tokens_ragged(const float *rppe, const float *dscale, const float *feats, const int32_t *idx,
@@ -219,10 +221,11 @@ int pda_max_pool_scatter_ragged(const float *grad_out, const uint8_t *arg, const
                                 const int32_t *off, float *grad_x, int64_t max_tokens, int64_t groups, int nsample,
                                 int d, pda_stream_t stream);
 int pda_group_attention_ragged_fwd(const float *qkv, const int32_t *cnt, const int32_t *off, float *out, float *lse,
-                                   int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream);
+                                   int64_t tokens, int64_t num_groups, int seq, int heads, int head_dim,
+                                   pda_stream_t stream);
 int pda_group_attention_ragged_bwd(const float *qkv, const float *grad_out, const float *lse, const int32_t *cnt,
-                                   const int32_t *off, float *grad_qkv, int64_t num_groups, int seq, int heads,
-                                   int head_dim, pda_stream_t stream);
+                                   const int32_t *off, float *grad_qkv, int64_t tokens, int64_t num_groups, int seq,
+                                   int heads, int head_dim, pda_stream_t stream);
 
 /* ---- DensityNet in training mode (MI355X extension) ----------------------------------------------
  * pointnet2_modules.py:958-981: y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) with 1x1 convs

@@ -9,7 +9,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # PDA_LIB_PATH: load another build of the same ABI (A/B timing of kernel variants)
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
@@ -103,8 +103,8 @@ SIGNATURES = {
     "pda_bn_relu_bwd_weighted": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _vp],
     "pda_add_max_pool_ragged": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_max_pool_scatter_ragged": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _vp],
-    "pda_group_attention_ragged_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
-    "pda_group_attention_ragged_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _vp],
+    "pda_group_attention_ragged_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp],
+    "pda_group_attention_ragged_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_densitynet_param_count": [],
     "pda_densitynet_scratch_bytes": [],
     "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],

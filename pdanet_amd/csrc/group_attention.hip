@@ -51,13 +51,15 @@ struct Tile {
     static constexpr int RPI = 64 / LPR;  // rows per wave instruction
     static constexpr int NI = HD / 8;     // wave instructions per 32-row tile
 
-    template <class RowPtr>
-    __device__ __forceinline__ static void load(float4 (&raw)[NI], RowPtr row_ptr, int lane) {
+    // row_off(r, valid): element offset of tile row r from `base` (wave-uniform pointer, 32-bit lane offsets: one address
+    // register per load instead of two, and no 64-bit lane arithmetic); always dereferenceable (clamped)
+    template <class TIO, class RowOff>
+    __device__ __forceinline__ static void load(float4 (&raw)[NI], const TIO* base, RowOff row_off, int lane) {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             bool valid;
-            const auto* p = row_ptr(it * RPI + lane / LPR, valid);  // always dereferenceable (clamped)
-            const float4 v = load4(p + 4 * (lane % LPR));
+            const unsigned o = row_off(it * RPI + lane / LPR, valid) + 4u * (unsigned)(lane % LPR);
+            const float4 v = load4(base + o);
             raw[it] = valid ? v : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
@@ -80,90 +82,60 @@ struct Tile {
         for (int q = 0; q < 4; ++q)
             *reinterpret_cast<float4*>(dst + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
     }
-    template <class RowPtr>
-    __device__ __forceinline__ static void store(const float* lds, RowPtr row_ptr, int lane) {
+    template <class TIO, class RowOff>
+    __device__ __forceinline__ static void store(const float* lds, TIO* base, RowOff row_off, int lane) {
 #pragma unroll
         for (int it = 0; it < NI; ++it) {
             const int r = it * RPI + lane / LPR;
-            auto* p = row_ptr(r);
+            bool valid;
+            const unsigned o = row_off(r, valid) + 4u * (unsigned)(lane % LPR);
             const float4 v = *reinterpret_cast<const float4*>(lds + r * LD + 4 * (lane % LPR));
-            if (p) store4(p + 4 * (lane % LPR), v);
+            if (valid) store4(base + o, v);
         }
     }
 };
 
-// S: tokens per group (8, 16 or 32).  A wave covers G = 32/S groups of one head.
-// RAGGED (csrc/ragged.hip): the rows are COMPACT -- group b owns rows [off[b], off[b] + cnt[b]), cnt[b] <= S distinct
-// tokens; slots >= cnt[b] are the repeats of token 0 the dense layout would hold.  They are not computed: their keys
-// are masked and key 0 enters the softmax with weight S - cnt + 1 (score + log of it), which is exactly the sum over
-// the repeated keys; their queries (identical to query 0) are not evaluated.  The tile logic is unchanged.
+// One 32-row tile of one head: rows [base, base + rows) of the (compact or dense) token axis, holding whole groups.
+// Per lane (operand column / query c = lane & 31): lo = first tile row of its group, n = tokens of its group, gid = the
+// group; a lane past `rows` has lo = c, n = 1 (its own zeroed row as the only key: the unused column stays finite and
+// contributes zeros to every contraction over queries).
+// RAGGED (csrc/ragged.hip): a group's rows are its cnt <= S DISTINCT tokens; the S - cnt repeats of token 0 the dense
+// layout would hold are not computed: key 0 enters the softmax with weight S - cnt + 1 (score + log of it), which is
+// exactly the sum over the repeated keys; their queries (identical to query 0) are not evaluated.
 template <int S, int HD, bool BWD, typename TIO, bool RAGGED>
-__global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __restrict__ qkv, const TIO* __restrict__ dout,
-                                                               TIO* __restrict__ out, float* __restrict__ lse,
-                                                               TIO* __restrict__ dqkv, int64_t nb, int H, float scale,
-                                                               const int32_t* __restrict__ cnt, const int32_t* __restrict__ off) {
-    constexpr int G = 32 / S;
+__device__ __forceinline__ void group_attention_tile(const TIO* __restrict__ qkv, const TIO* __restrict__ dout,
+                                                     TIO* __restrict__ out, float* __restrict__ lse, TIO* __restrict__ dqkv,
+                                                     int H, int head, float scale, float* lds, int lane, int64_t base, int rows,
+                                                     int lo, int n, int64_t gid) {
     using TL = Tile<HD>;
-    constexpr int TRN = 2 * 32 * 33;  // P and dS transposes (backward), stride 33
-    constexpr int LDSW = (BWD && TRN > 32 * TL::LD) ? TRN : 32 * TL::LD;
-    __shared__ __attribute__((aligned(16))) float lds_all[4][LDSW];  // wave-private images: no barriers
-    const int w = wave_id(), lane = lane_id();
-    float* lds = lds_all[w];
     const int c = lane & 31, h2 = lane >> 5;
-    const int64_t task = (int64_t)blockIdx.x * 4 + w;      // (group-block, head)
-    const int head = (int)(task % H);
-    const int64_t b0 = (task / H) * G;                      // first group of this wave
-    if (b0 >= nb) return;
-    // RAGGED: tokens and first compact row of the wave's G groups (wave-uniform); a group past the end has 0 tokens
-    int gn[G];
-    int64_t go[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const bool gv = b0 + g < nb;
-        gn[g] = RAGGED ? (gv ? cnt[b0 + g] : 0) : (gv ? S : 0);
-        go[g] = RAGGED ? off[gv ? b0 + g : b0] : (b0 + g) * S;
-    }
-    auto g_n = [&](int g) -> int { int v = gn[0];
-#pragma unroll
-        for (int q = 1; q < G; ++q) v = g == q ? gn[q] : v;
-        return v; };
-    auto g_o = [&](int g) -> int64_t { int64_t v = go[0];
-#pragma unroll
-        for (int q = 1; q < G; ++q) v = g == q ? go[q] : v;
-        return v; };
-    // tile row r = (group r / S, slot r % S) -> its row in HBM; invalid rows read group b0's token 0 and are zeroed
-    auto tile_row = [&](int r, bool& valid) -> int64_t {
-        const int g = r / S, sl_ = r % S;
-        valid = sl_ < g_n(g);
-        return valid ? g_o(g) + sl_ : go[0];
-    };
-    // my column / row as operand lane: group g = c / S, token s = c % S
-    const int64_t bl = b0 + c / S;
-    const int sl = c % S;
-    const bool ok = bl < nb && sl < g_n(c / S);
-    // row r of the wave's 32-token tile
-    // Loads never branch on validity (a divergent branch around a load serialises load -> wait ->
-    // MFMA): rows of groups past the end read group b0's row instead and are zeroed by a select.
+    const bool ok = c < rows;
+    const int sl = c - lo;
+    // the tile's first row in HBM (wave-uniform pointers) and element offsets of tile row r from it; rows past the end read
+    // row `base` instead and are zeroed by a select (loads never branch on validity: a divergent branch around a load
+    // serialises load -> wait -> MFMA)
+    const TIO* qb = qkv + GaPtrs<HD>::qkv(H, (size_t)base, 0, head);
+    const TIO* dob = BWD ? dout + GaPtrs<HD>::o(H, (size_t)base, head) : nullptr;
+    const unsigned OS = (unsigned)(H * HD), RS = 3u * OS;   // elements per out / qkv row
     auto in_row = [&](int which) {
-        return [&, which](int r, bool& valid) -> const TIO* {
-            return qkv + GaPtrs<HD>::qkv(H, (size_t)tile_row(r, valid), which, head);
+        return [&, which](int r, bool& valid) -> unsigned {
+            valid = r < rows;
+            return (valid ? (unsigned)r * RS : 0u) + (unsigned)which * OS;
         };
     };
-    auto do_row = [&](int r, bool& valid) -> const TIO* {
-        return dout + GaPtrs<HD>::o(H, (size_t)tile_row(r, valid), head);
+    auto o_row = [&](int r, bool& valid) -> unsigned {
+        valid = r < rows;
+        return valid ? (unsigned)r * OS : 0u;
     };
-    // key j of the tile as seen by my query column: inside my group and a real (distinct) token?  bias = log of the
-    // multiplicity of key 0 (RAGGED); a group past the end keeps key 0 so that its (unused) column stays finite
-    auto key_ok = [&](int j) -> bool {
-        return (j / S) == (c / S) && (j % S) < max(g_n(j / S), 1);
-    };
-    const float lnw = RAGGED ? __logf((float)(S - max(g_n(c / S), 1) + 1)) : 0.f;
+    // key j of the tile as seen by my query column: a token of my group?
+    auto key_ok = [&](int j) -> bool { return j >= lo && j < lo + n; };
+    const float lnw = (RAGGED && ok) ? __logf((float)(S - n + 1)) : 0.f;   // log of the multiplicity of key 0
 
     float kq[HD / 2], qq[HD / 2];
     {
         float4 rk[TL::NI], rq[TL::NI];
-        TL::load(rk, in_row(1), lane);
-        TL::load(rq, in_row(0), lane);
+        TL::load(rk, qb, in_row(1), lane);
+        TL::load(rq, qb, in_row(0), lane);
         TL::to_operand(kq, rk, lds, lane);  // A operand: rows j = keys
         TL::to_operand(qq, rq, lds, lane);  // B operand: cols i = queries
     }
@@ -181,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = acc_row(r, h2);
-            T[r] = key_ok(j) ? T[r] * scale + ((RAGGED && (j % S) == 0) ? lnw : 0.f) : -__builtin_inff();
+            T[r] = key_ok(j) ? T[r] * scale + ((RAGGED && j == lo) ? lnw : 0.f) : -__builtin_inff();
             m = fmaxf(m, T[r]);
         }
         m = fmaxf(m, __shfl_xor(m, 32));
@@ -193,21 +165,21 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) P[r] *= inv;
         lse_i = m + __logf(l);
-        if (ok && h2 == 0) lse[(bl * H + head) * S + sl] = lse_i;
+        if (ok && h2 == 0) lse[(gid * H + head) * S + sl] = lse_i;
     } else {
-        lse_i = ok ? lse[(bl * H + head) * S + sl] : 0.f;
+        lse_i = ok ? lse[(gid * H + head) * S + sl] : 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int j = acc_row(r, h2);
-            P[r] = key_ok(j) ? __expf(T[r] * scale + ((RAGGED && (j % S) == 0) ? lnw : 0.f) - lse_i) : 0.f;
+            P[r] = key_ok(j) ? __expf(T[r] * scale + ((RAGGED && j == lo) ? lnw : 0.f) - lse_i) : 0.f;
         }
     }
 
     // A operand fetched in accumulator key order: x[key j(t,h2)][dblk*32 + c] (128-byte rows per half wave)
     auto key_val = [&](int which, int t, int col) -> float {
         bool valid;
-        const int64_t row = tile_row(acc_row(t, h2), valid);
-        const float v = load1(qkv + GaPtrs<HD>::qkv(H, (size_t)row, which, head) + col);
+        const unsigned o = in_row(which)(acc_row(t, h2), valid) + (unsigned)col;
+        const float v = load1(qb + o);
         return valid ? v : 0.f;
     };
 
@@ -224,19 +196,14 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             }
             TL::from_acc(lds, O, dblk, lane);
         }
-        TL::store(lds, [&](int r) -> TIO* {
-            bool valid;
-            const int64_t row = tile_row(r, valid);
-            return valid ? out + GaPtrs<HD>::o(H, (size_t)row, head) : nullptr;
-        }, lane);
-        return;
+        TL::store(lds, out + GaPtrs<HD>::o(H, (size_t)base, head), o_row, lane);
     } else {
         // dP^T[j][i] = sum_d V[j][d] dO^T[d][i]
         float vv[HD / 2], dd[HD / 2];
         {
             float4 rv[TL::NI], rd[TL::NI];
-            TL::load(rv, in_row(2), lane);
-            TL::load(rd, do_row, lane);
+            TL::load(rv, qb, in_row(2), lane);
+            TL::load(rd, dob, o_row, lane);
             TL::to_operand(vv, rv, lds, lane);
             TL::to_operand(dd, rd, lds, lane);
         }
@@ -269,17 +236,11 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
         }
         auto qry_o_val = [&](int t, int col) -> float {  // dO[query i(t,h2)][col]
             bool valid;
-            const int64_t row = tile_row(acc_row(t, h2), valid);
-            const float v = load1(dout + GaPtrs<HD>::o(H, (size_t)row, head) + col);
+            const unsigned o = o_row(acc_row(t, h2), valid) + (unsigned)col;
+            const float v = load1(dob + o);
             return valid ? v : 0.f;
         };
-        auto out_row = [&](int which) {
-            return [&, which](int r) -> TIO* {
-                bool valid;
-                const int64_t row = tile_row(r, valid);
-                return valid ? dqkv + GaPtrs<HD>::qkv(H, (size_t)row, which, head) : nullptr;
-            };
-        };
+        TIO* dqb = dqkv + GaPtrs<HD>::qkv(H, (size_t)base, 0, head);
         // dQ^T = K^T dS^T
 #pragma unroll
         for (int dblk = 0; dblk < HD / 32; ++dblk) {
@@ -292,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             }
             TL::from_acc(lds, acc, dblk, lane);
         }
-        TL::store(lds, out_row(0), lane);
+        TL::store(lds, dqb, in_row(0), lane);
         // dK^T = Q^T dS
 #pragma unroll
         for (int dblk = 0; dblk < HD / 32; ++dblk) {
@@ -305,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             }
             TL::from_acc(lds, acc, dblk, lane);
         }
-        TL::store(lds, out_row(1), lane);
+        TL::store(lds, dqb, in_row(1), lane);
         // dV^T = dO^T P
 #pragma unroll
         for (int dblk = 0; dblk < HD / 32; ++dblk) {
@@ -318,21 +279,87 @@ __global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __re
             }
             TL::from_acc(lds, acc, dblk, lane);
         }
-        TL::store(lds, out_row(2), lane);
+        TL::store(lds, dqb, in_row(2), lane);
+    }
+}
+
+// Groups one wave owns (kb): dense, the 32/S groups of one tile; RAGGED, kb consecutive groups whose distinct tokens it
+// packs greedily into as few 32-row tiles as they need (round 3: a group of 32 slots holds ~10 distinct tokens on the
+// ONCE scenes, so one group per tile left two thirds of every MFMA and of every load slot empty).  The launcher picks kb
+// from the mean count: the groups that fill ONE tile on average (a wave that walks several tiles runs them back to back
+// with nothing overlapping its loads; separate waves overlap each other: measured, a second tile per wave costs 10-20 %),
+// more -- up to GA_BLOCK_ROWS distinct tokens -- only while at least GA_MIN_WAVES waves remain.
+constexpr int GA_BLOCK_ROWS = 128;
+constexpr int64_t GA_MIN_WAVES = 8192;
+
+// S: tokens per group (8, 16 or 32).  RAGGED: the rows are COMPACT -- group b owns rows [off[b], off[b] + cnt[b]).
+template <int S, int HD, bool BWD, typename TIO, bool RAGGED>
+__global__ __launch_bounds__(256, 2) void group_attention_kernel(const TIO* __restrict__ qkv, const TIO* __restrict__ dout,
+                                                               TIO* __restrict__ out, float* __restrict__ lse,
+                                                               TIO* __restrict__ dqkv, int64_t nb, int H, float scale,
+                                                               const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
+                                                               int kb) {
+    const int KB = RAGGED ? kb : 32 / S;
+    using TL = Tile<HD>;
+    constexpr int TRN = 2 * 32 * 33;  // P and dS transposes (backward), stride 33
+    constexpr int LDSW = (BWD && TRN > 32 * TL::LD) ? TRN : 32 * TL::LD;
+    __shared__ __attribute__((aligned(16))) float lds_all[4][LDSW];  // wave-private images: no barriers
+    const int w = wave_id(), lane = lane_id();
+    float* lds = lds_all[w];
+    const int c = lane & 31;
+    const int64_t task = (int64_t)blockIdx.x * 4 + w;      // (group block, head)
+    const int head = (int)(task % H);
+    const int64_t b0 = (task / H) * KB;                     // first group of this wave
+    if (b0 >= nb) return;
+    if (!RAGGED) {
+        const int rows = (int)min((int64_t)KB, nb - b0) * S;
+        group_attention_tile<S, HD, BWD, TIO, false>(qkv, dout, out, lse, dqkv, H, head, scale, lds, lane, b0 * S, rows,
+                                                     c < rows ? (c / S) * S : c, c < rows ? S : 1, b0 + c / S);
+    } else {
+        const int64_t bend = min(nb, b0 + (int64_t)KB);
+        int64_t g = b0;
+#pragma nounroll
+        while (g < bend) {                                  // every pass takes its first group (cn <= 32, off[g] == base): the loop ends
+            // the lane number is re-defined opaquely in every pass: the ~250 per-lane offsets the tile derives from it are loop
+            // invariants otherwise, and hoisted out of the loop they stay live across it (HD = 128 backward: 492 bytes of scratch)
+            int lv = lane;
+            asm volatile("" : "+v"(lv));
+            const int c = lv & 31;
+            const int64_t base = off[g];
+            int rows = 0, lo = c, n = 1;
+            int64_t gid = g;
+            do {                                            // wave-uniform: the groups that still fit into this tile
+                const int cn = min(max(cnt[g], 0), S);
+                if (rows + cn > 32 || off[g] != base + rows) break;
+                if (c >= rows && c < rows + cn) { lo = rows; n = cn; gid = g; }
+                rows += cn;
+                ++g;
+            } while (g < bend);
+            if (rows > 0)
+                group_attention_tile<S, HD, BWD, TIO, true>(qkv, dout, out, lse, dqkv, H, head, scale, lds, lv, base, rows, lo,
+                                                            n, gid);
+        }
     }
 }
 
 template <bool BWD, typename TIO, bool RAGGED = false>
 static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, float* lse, TIO* dqkv,
                                   int64_t nb, int s, int h, int hd, hipStream_t stream, const char* what,
-                                  const int32_t* cnt = nullptr, const int32_t* off = nullptr) {
+                                  const int32_t* cnt = nullptr, const int32_t* off = nullptr, int64_t tokens = 0) {
     PDA_REQUIRE(nb >= 0 && h >= 1, "%s: bad size", what);
     if (nb == 0) return PDA_OK;
     PDA_REQUIRE(qkv && lse && (BWD ? (dout && dqkv) : (out != nullptr)), "%s: null pointer", what);
     PDA_REQUIRE(!RAGGED || (cnt && off), "%s: null pointer", what);
-    const int G = 32 / (s > 0 ? s : 1);
+    PDA_REQUIRE(s >= 1 && s <= 32 && tokens >= 0, "%s: bad size", what);
+    int G = 32 / s;                                           // groups per wave (group_attention_kernel)
+    if (RAGGED) {
+        const int64_t mean = std::max<int64_t>(1, std::min<int64_t>(s, divup64(tokens, nb)));
+        const int64_t cap = std::max<int64_t>(1, nb * h / GA_MIN_WAVES);
+        G = (int)std::max<int64_t>(32 / mean, std::min<int64_t>(GA_BLOCK_ROWS / mean, cap));
+        G = std::max(1, std::min(G, 64));
+    }
     const float scale = 1.0f / sqrtf((float)hd);
-    void (*kern)(const TIO*, const TIO*, TIO*, float*, TIO*, int64_t, int, float, const int32_t*, const int32_t*) = nullptr;
+    void (*kern)(const TIO*, const TIO*, TIO*, float*, TIO*, int64_t, int, float, const int32_t*, const int32_t*, int) = nullptr;
 #define PDA_GA_CASE(SS, DD) if (s == SS && hd == DD) kern = group_attention_kernel<SS, DD, BWD, TIO, RAGGED>
     PDA_GA_CASE(32, 64); PDA_GA_CASE(16, 64); PDA_GA_CASE(8, 64);
     PDA_GA_CASE(32, 128); PDA_GA_CASE(16, 128); PDA_GA_CASE(8, 128);
@@ -345,7 +372,7 @@ static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, flo
     const int64_t tasks = divup64(nb, G) * h;
     const int64_t blocks = divup64(tasks, 4);
     PDA_REQUIRE(blocks < INT32_MAX, "%s: too many groups", what);
-    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, qkv, dout, out, lse, dqkv, nb, h, scale, cnt, off);
+    hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, stream, qkv, dout, out, lse, dqkv, nb, h, scale, cnt, off, G);
     return check_launch(what);
 }
 
@@ -377,14 +404,16 @@ PDA_API int pda_group_attention_bwd_bf16(const uint16_t* qkv, const uint16_t* gr
 
 // Compact ("ragged") rows: qkv (U, 3, H, hd), out / grad (U, H * hd), lse (groups, H, seq); see csrc/ragged.hip.
 PDA_API int pda_group_attention_ragged_fwd(const float* qkv, const int32_t* cnt, const int32_t* off, float* out, float* lse,
-                                           int64_t num_groups, int seq, int heads, int head_dim, pda_stream_t stream) {
+                                           int64_t tokens, int64_t num_groups, int seq, int heads, int head_dim,
+                                           pda_stream_t stream) {
     return pda::launch_group_attention<false, float, true>(qkv, nullptr, out, lse, nullptr, num_groups, seq, heads, head_dim,
-                                                           (hipStream_t)stream, "pda_group_attention_ragged_fwd", cnt, off);
+                                                           (hipStream_t)stream, "pda_group_attention_ragged_fwd", cnt, off, tokens);
 }
 
 PDA_API int pda_group_attention_ragged_bwd(const float* qkv, const float* grad_out, const float* lse, const int32_t* cnt,
-                                           const int32_t* off, float* grad_qkv, int64_t num_groups, int seq, int heads,
-                                           int head_dim, pda_stream_t stream) {
+                                           const int32_t* off, float* grad_qkv, int64_t tokens, int64_t num_groups, int seq,
+                                           int heads, int head_dim, pda_stream_t stream) {
     return pda::launch_group_attention<true, float, true>(qkv, grad_out, nullptr, const_cast<float*>(lse), grad_qkv, num_groups, seq,
-                                                          heads, head_dim, (hipStream_t)stream, "pda_group_attention_ragged_bwd", cnt, off);
+                                                          heads, head_dim, (hipStream_t)stream, "pda_group_attention_ragged_bwd", cnt, off,
+                                                          tokens);
 }

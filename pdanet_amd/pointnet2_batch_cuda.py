@@ -676,7 +676,7 @@ def group_attention_ragged_fwd(qkv, cnt, off, out, lse, tokens, num_groups, seq,
     _numel_ok(qkv, tokens * 3 * heads * head_dim, "qkv"); _numel_ok(out, tokens * heads * head_dim, "out")
     _numel_ok(lse, num_groups * heads * seq, "lse"); _numel_ok(cnt, num_groups, "cnt"); _numel_ok(off, num_groups + 1, "off")
     _call("pda_group_attention_ragged_fwd", qkv, _chk(qkv, "qkv", F32), _chk(cnt, "cnt", I32), _chk(off, "off", I32),
-          _chk(out, "out", F32), _chk(lse, "lse", F32), num_groups, seq, heads, head_dim)
+          _chk(out, "out", F32), _chk(lse, "lse", F32), tokens, num_groups, seq, heads, head_dim)
     return 1
 
 
@@ -684,7 +684,7 @@ def group_attention_ragged_bwd(qkv, grad_out, lse, cnt, off, grad_qkv, tokens, n
     _numel_ok(qkv, tokens * 3 * heads * head_dim, "qkv"); _numel_ok(grad_qkv, tokens * 3 * heads * head_dim, "grad_qkv")
     _numel_ok(grad_out, tokens * heads * head_dim, "grad_out"); _numel_ok(lse, num_groups * heads * seq, "lse")
     _call("pda_group_attention_ragged_bwd", qkv, _chk(qkv, "qkv", F32), _chk(grad_out, "grad_out", F32), _chk(lse, "lse", F32),
-          _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_qkv, "grad_qkv", F32), num_groups, seq, heads, head_dim)
+          _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_qkv, "grad_qkv", F32), tokens, num_groups, seq, heads, head_dim)
     return 1
 
 

@@ -35,7 +35,7 @@ def test_binding_covers_header():
 
 
 def test_info_entry_points(lib, oracle):
-    assert lib.pda_abi_version() == 19
+    assert lib.pda_abi_version() == 20
     assert lib.pda_fp_contract_mode() == 1
     for n in [1, 2, 3, 7, 8, 100, 1000, 1023, 1024, 4096, 16384, 60000, 65536]:
         assert lib.pda_opt_n_threads(n) == oracle.opt_n_threads(n)

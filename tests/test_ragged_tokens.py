@@ -48,13 +48,20 @@ def test_plan_matches_numpy(G, S):
     assert np.array_equal(plan.rowmap.cpu().numpy(), rowmap)
 
 
-@pytest.mark.parametrize("S,hd,heads", [(8, 32, 4), (16, 64, 4), (32, 64, 4), (32, 128, 4), (16, 128, 2)])
-def test_ragged_attention_equals_dense_attention_on_padded_groups(S, hd, heads):
+# The ragged kernel packs the distinct tokens of consecutive groups into 32-row tiles, several groups (chosen from the mean
+# count) per wave: the count distributions below make a wave's groups fit one tile exactly (all single: 32 groups of 1),
+# never share a tile (all full at S = 32), overflow into a second tile, end in a ragged last block (G not a multiple of
+# the groups per wave), and -- the large case -- walk several tiles per wave.
+@pytest.mark.parametrize("S,hd,heads,G,p_single,p_full", [
+    (8, 32, 4, 203, 0.3, 0.1), (16, 64, 4, 203, 0.3, 0.1), (32, 64, 4, 203, 0.3, 0.1), (32, 128, 4, 203, 0.3, 0.1),
+    (16, 128, 2, 203, 0.3, 0.1), (32, 64, 4, 333, 1.0, 0.0), (32, 64, 4, 131, 0.0, 1.0), (16, 32, 4, 131, 0.0, 1.0),
+    (8, 32, 4, 1001, 0.9, 0.1), (16, 32, 4, 20011, 0.0, 0.0)])
+def test_ragged_attention_equals_dense_attention_on_padded_groups(S, hd, heads, G, p_single, p_full):
     """Dense kernel on the (G, S) layout with token 0 repeated == ragged kernel on the compact rows."""
     from pdanet_amd import pointnet2_utils as pu, pointnet2_batch_cuda as ext
-    G, D = 203, heads * hd
-    rng = np.random.default_rng(S * 10 + hd)
-    idx, cnt = padded_idx(G, S, 4000, rng)
+    D = heads * hd
+    rng = np.random.default_rng(S * 10 + hd + G)
+    idx, cnt = padded_idx(G, S, 4000, rng, p_single, p_full, empty_rows=2 if p_full < 1.0 else 0)
     (plan,) = pu.ragged_plans([torch.from_numpy(idx).cuda().view(1, G, S)])
     U = plan.tokens
     torch.manual_seed(S + hd)
