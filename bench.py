@@ -283,6 +283,9 @@ def main():
                     extra[xname]["roofline_mfma_fused_sa"] = xr["roofline"]
                 if xname == "backbone_infer":
                     extra[xname]["graph_tail_infer"] = bool(getattr(xw.model, "graph_tail_infer", False))
+                if hasattr(xw, "host_bound"):       # which form the probe of this workload chose (workloads.py)
+                    extra[xname].update(host_bound_at_probe=bool(xw.host_bound), graph_tail=bool(xw.model.graph_tail),
+                                        graph_head=bool(getattr(xw.model, "graph_head", False)))
                 del xw
             except Exception as e:  # noqa: BLE001  (a secondary timing must not cost the headline line)
                 print("bench.py: extra workload %s failed: %r" % (xname, e), file=sys.stderr)

@@ -756,6 +756,8 @@ class DetectorTrainWorkload(TrainStepWorkload):
             torch.cuda.synchronize()
             t2 = time.perf_counter()
             self.host_bound = (t1 - t0) > 0.93 * (t2 - t0)      # the GPU was done (almost) as soon as the host was
+            if os.environ.get("PDA_PROBE_FORCE") in ("0", "1"):   # test hook: the probe's verdict, whatever the box
+                self.host_bound = os.environ["PDA_PROBE_FORCE"] == "1"
             self.model.graph_tail = self.host_bound
             self._tail_auto = False
         # DETACHED: a caller that keeps the returned loss (`loss = wl.step()` in a loop) must not keep the iteration's autograd
