@@ -73,17 +73,51 @@ def time_workload(wl, steps, warmup, device, parallel):
     """W (+2 priming) untimed steps, then exactly K steps between barrier + synchronize on both sides; MAX over
     ranks.  The two priming steps keep first-use costs (code-object loading of every library GEMM, allocator
     growth, TunableOp table lookups) out of a run with a small W."""
+    trace = [] if os.environ.get("PDA_BENCH_STEP_TIMES") else None     # host-side enqueue time of every step -> stderr
+    if trace is not None:
+        import gc
+        gcs = []
+
+        def on_gc(phase, info, _t=[0.0]):
+            if phase == "start":
+                _t[0] = time.perf_counter()
+            else:
+                gcs.append((len(trace), info["generation"], 1e3 * (time.perf_counter() - _t[0]), info["collected"]))
+        gc.callbacks.append(on_gc)
     wl.begin()
     for _ in range(2 + warmup):
+        ts = time.perf_counter()
         wl.step()
+        if trace is not None:
+            trace.append(time.perf_counter() - ts)
+    # What is alive after the warm-up (modules, captured graphs, cached plans and packed weights: ~10^6 objects by the fourth
+    # workload of a run) is taken out of the collector's generations, as a long-running training loop does after start-up:
+    # a generation-2 pass that walks all of it costs the host 82 ms (measured with gc.callbacks, PDA_BENCH_STEP_TIMES=1), once per
+    # ~10 iterations of the host-bound KITTI workload -- 6 ms per step over a 10-step window.  The collector stays on for what
+    # the steps themselves allocate.  PDA_GC_FREEZE=0: leave it alone.
+    import gc
+    frozen = os.environ.get("PDA_GC_FREEZE", "1") != "0"
+    if frozen:
+        gc.collect()
+        gc.freeze()
     parallel.barrier(device)
     wl.record = True
     t0 = time.perf_counter()
     for _ in range(steps):
+        ts = time.perf_counter()
         wl.step()
+        if trace is not None:
+            trace.append(time.perf_counter() - ts)
     parallel.barrier(device)
     dt = time.perf_counter() - t0
     wl.record = False
+    if frozen:
+        gc.unfreeze()
+    if trace is not None:
+        gc.callbacks.remove(on_gc)
+        print("bench.py: %s collections (step, generation, ms, objects): %s" % (wl.name, [g for g in gcs if g[2] > 1.0]), file=sys.stderr)
+        print("bench.py: %s host ms per step (warm-up %d): %s" % (wl.name, 2 + warmup, " ".join("%.1f" % (1e3 * t) for t in trace)),
+              file=sys.stderr)
     return parallel.max_over_ranks(dt, device)
 
 

@@ -243,6 +243,22 @@ int pda_densitynet_fwd(const float *x, const float *params, float *y, float *sta
                        pda_stream_t stream);
 int pda_densitynet_bwd(const float *x, const float *grad_y, const float *params, const float *stats,
                        float *grad_params, void *scratch, int64_t n, float eps, pda_stream_t stream);
+/* The same on the DISTINCT slots of padded neighbour lists (pda_ragged_plan above): x, y, grad_y keep the dense
+ * (groups, nsample) layout, n = groups * nsample, but only the *n_unique slots rowmap[0..) are evaluated, slot 0 of a
+ * group standing for its row_weight = nsample - cnt + 1 identical tokens (ball_query's repeats, slots cnt..nsample-1,
+ * hold the same x).  n_unique is DEVICE memory (off + groups of the plan): no host read.  Batch statistics, running
+ * statistics and parameter gradients are those of the n dense tokens; forward writes every slot of y (a group's
+ * repeats together with its slot 0); backward takes the gradient of a distinct slot as the sum over its copies.
+ * Results equal pda_densitynet_fwd / _bwd up to the order of the floating-point additions. */
+int pda_densitynet_fwd_unique(const float *x, const float *params, float *y, float *stats, void *scratch,
+                              float *running_mean1, float *running_var1, float *running_mean2, float *running_var2,
+                              float *running_mean3, float *running_var3, int64_t n, const int32_t *rowmap,
+                              const float *row_weight, const int32_t *n_unique, int nsample, float eps, float momentum,
+                              pda_stream_t stream);
+int pda_densitynet_bwd_unique(const float *x, const float *grad_y, const float *params, const float *stats,
+                              float *grad_params, void *scratch, int64_t n, const int32_t *rowmap,
+                              const float *row_weight, const int32_t *n_unique, int nsample, float eps,
+                              pda_stream_t stream);
 
 /* PDA grouper geometry (MI355X extension; pointnet2_utils.py:590-607, pointnet2_modules.py:905-913,:1000-1001),
  * point-major: xyz (B,N,3), new_xyz (B,M,3), idx (B,M,nsample) -> rppe (B,M,nsample,12) = [centre, neighbour,

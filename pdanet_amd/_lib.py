@@ -109,6 +109,8 @@ SIGNATURES = {
     "pda_densitynet_scratch_bytes": [],
     "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],
     "pda_densitynet_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _vp],
+    "pda_densitynet_fwd_unique": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _i, _f, _f, _vp],
+    "pda_densitynet_bwd_unique": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _i, _f, _vp],
     "pda_pda_geometry": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],
     "pda_points_in_boxes": [_vp, _vp, _vp, _i, _i, _i, _vp],
     "pda_assign_point_targets": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

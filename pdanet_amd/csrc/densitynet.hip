@@ -33,6 +33,21 @@ struct DnState {
     float p[DN_NPARAM];
 };
 
+// Which tokens a pass walks.  Dense (rowmap == nullptr): token t of n, every one on its own.  Unique (csrc/ragged.hip):
+// x / y / dy keep their dense (groups, ns) layout, but ball_query's repeats of a group's first neighbour (slots cnt..ns-1)
+// hold the same x as slot 0 and are not evaluated: the passes walk the *n_unique distinct slots rowmap[0..), slot 0
+// standing for roww = ns - cnt + 1 tokens.  Statistics are those of all n dense tokens (weighted sums); forward writes a
+// group's repeat slots along with its slot 0; backward takes a distinct slot's gradient as the SUM over its copies (every
+// BatchNorm-backward term that is per dense token, i.e. the two batch means, enters w times).  Results equal the dense
+// passes' up to the order of the float additions.
+struct DnRows {
+    const int32_t* rowmap;
+    const float* roww;
+    const int32_t* n_unique;   // device memory (off[groups] of the plan): no host read
+    int ns;
+};
+__device__ __forceinline__ int64_t dn_rows(const DnRows& R, int64_t n) { return R.rowmap ? (int64_t)*R.n_unique : n; }
+
 // block-wide sum of `cnt` per-thread doubles -> partial[blockIdx][k]
 // (a thread sees at most n / 65536 + 1 tokens, so its own running sums stay in float; everything across
 // lanes, waves and blocks is added in double)
@@ -140,7 +155,7 @@ __global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __rest
                                                              float* __restrict__ stats, double* __restrict__ part_in,
                                                              double* __restrict__ part_out, float* __restrict__ y, int64_t n,
                                                              float eps, float momentum, float* rm1, float* rv1, float* rm2,
-                                                             float* rv2, float* rm3, float* rv3, int nblocks) {
+                                                             float* rv2, float* rm3, float* rv3, int nblocks, DnRows R) {
     __shared__ float prm[DN_NPARAM];
     __shared__ float st[DN_NSTAT];
     __shared__ double sums[DN_MAXP];
@@ -197,10 +212,13 @@ __global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __rest
     float acc[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) acc[k] = 0;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
-        const float xv = x[t];
+    const int64_t rows = dn_rows(R, n);
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+        const int64_t e = R.rowmap ? R.rowmap[t] : t;
+        const float w = R.rowmap ? R.roww[t] : 1.f;
+        const float xv = x[e];
         if (PASS == 1) {
-            acc[0] += xv; acc[1] += xv * xv;
+            acc[0] += w * xv; acc[1] += w * (xv * xv);
         } else {
             DnFwd f;
             dn_layer1(prm, st, xv, f);
@@ -208,11 +226,16 @@ __global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __rest
                 float z2[DN_H2];
                 dn_z2(prm, f, z2);
 #pragma unroll
-                for (int j = 0; j < DN_H2; ++j) { acc[j] += z2[j]; acc[DN_H2 + j] += z2[j] * z2[j]; }
+                for (int j = 0; j < DN_H2; ++j) { acc[j] += w * z2[j]; acc[DN_H2 + j] += w * (z2[j] * z2[j]); }
             } else {
                 const float z3 = dn_layer2(prm, st, f);
-                if (PASS == 3) { acc[0] += z3; acc[1] += z3 * z3; }
-                else y[t] = fmaxf(((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3] * prm[DN_G3] + prm[DN_BE3], 0.f);
+                if (PASS == 3) { acc[0] += w * z3; acc[1] += w * (z3 * z3); }
+                else {
+                    const float yv = fmaxf(((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3] * prm[DN_G3] + prm[DN_BE3], 0.f);
+                    y[e] = yv;
+                    const int rep = (int)w - 1;                       // slot 0 of a short list: its repeats sit at the group's end
+                    for (int q = 0; q < rep; ++q) y[e + R.ns - rep + q] = yv;
+                }
             }
         }
     }
@@ -229,7 +252,7 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
                                                              const float* __restrict__ prm_g, const float* __restrict__ stats,
                                                              const double* __restrict__ p1, const double* __restrict__ p2,
                                                              const double* __restrict__ p3, double* __restrict__ part_out,
-                                                             int64_t n, float eps, int nblocks) {
+                                                             int64_t n, float eps, int nblocks, DnRows R) {
     __shared__ float prm[DN_NPARAM];
     __shared__ float st[DN_NSTAT];
     __shared__ double sums[DN_MAXP];
@@ -253,6 +276,15 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
         inv1[threadIdx.x] = (float)(1.0 / sqrt(w * w * (double)st[DN_VX] + (double)eps));
     }
     __syncthreads();
+    const int64_t rows = dn_rows(R, n);
+    // token t of the walk: its dense slot, multiplicity, and the gradient of all its copies
+    auto operands = [&](int64_t t, int64_t& e, float& w, float& g) {
+        e = R.rowmap ? R.rowmap[t] : t;
+        w = R.rowmap ? R.roww[t] : 1.f;
+        g = dy[e];
+        const int rep = (int)w - 1;
+        for (int q = 0; q < rep; ++q) g += dy[e + R.ns - rep + q];
+    };
     if (PASS == 3) {
         // dW2 is an 8 x 16 outer-product sum: 128 running sums per token-owning thread would not fit in registers.
         // Tokens are staged 256 at a time in LDS (h1[16], dz2[8], dyh1[16], xh) and thread k < 168 owns ONE of the
@@ -260,21 +292,25 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
         __shared__ float stage[256][DN_H1 + DN_H2 + DN_H1 + 1];
         double mine = 0;
         const int k = threadIdx.x;
-        for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < n; t0 += (int64_t)gridDim.x * 256) {
+        for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < rows; t0 += (int64_t)gridDim.x * 256) {
             const int64_t t = t0 + threadIdx.x;
             float* sp = stage[threadIdx.x];
-            if (t < n) {
+            if (t < rows) {
+                int64_t e;
+                float w, gy;
+                operands(t, e, w, gy);
+                const double wd = (double)w;
                 DnFwd f;
-                dn_layer1(prm, st, x[t], f);
+                dn_layer1(prm, st, x[e], f);
                 const float z3 = dn_layer2(prm, st, f);
                 f.z3h = ((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3];
-                const float dyh3 = (f.z3h * prm[DN_G3] + prm[DN_BE3]) > 0.f ? dy[t] : 0.f;
-                const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - m3[0] - (double)f.z3h * m3[1]);
+                const float dyh3 = (f.z3h * prm[DN_G3] + prm[DN_BE3]) > 0.f ? gy : 0.f;
+                const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - wd * m3[0] - wd * ((double)f.z3h * m3[1]));
                 float dz2[DN_H2];
 #pragma unroll
                 for (int j = 0; j < DN_H2; ++j) {
                     const float dyh2 = f.h2[j] > 0.f ? prm[DN_W3 + j] * dz3 : 0.f;
-                    dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2 - m2[j] - (double)f.z2h[j] * m2[DN_H2 + j]);
+                    dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2 - wd * m2[j] - wd * ((double)f.z2h[j] * m2[DN_H2 + j]));
                     sp[DN_H1 + j] = dz2[j];
                 }
 #pragma unroll
@@ -319,15 +355,20 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
     float acc[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) acc[k] = 0;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+        int64_t e;
+        float w, gy;
+        operands(t, e, w, gy);
+        const double wd = (double)w;
+        const float xv = x[e];
         DnFwd f;
-        dn_layer1(prm, st, x[t], f);
+        dn_layer1(prm, st, xv, f);
         const float z3 = dn_layer2(prm, st, f);
         f.z3h = ((z3 - st[DN_M3]) - st[DN_M3L]) * st[DN_I3];
         const float yv = f.z3h * prm[DN_G3] + prm[DN_BE3];
-        const float dyh3 = yv > 0.f ? dy[t] : 0.f;
+        const float dyh3 = yv > 0.f ? gy : 0.f;
         if (PASS == 1) { acc[0] += dyh3; acc[1] += dyh3 * f.z3h; continue; }
-        const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - m3[0] - (double)f.z3h * m3[1]);
+        const float dz3 = prm[DN_G3] * st[DN_I3] * (float)((double)dyh3 - wd * m3[0] - wd * ((double)f.z3h * m3[1]));
         float dyh2[DN_H2];
 #pragma unroll
         for (int j = 0; j < DN_H2; ++j) dyh2[j] = f.h2[j] > 0.f ? prm[DN_W3 + j] * dz3 : 0.f;
@@ -340,7 +381,7 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
         // PASS == 4
         float dz2[DN_H2];
 #pragma unroll
-        for (int j = 0; j < DN_H2; ++j) dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2[j] - m2[j] - (double)f.z2h[j] * m2[DN_H2 + j]);
+        for (int j = 0; j < DN_H2; ++j) dz2[j] = prm[DN_G2 + j] * st[DN_I2 + j] * (float)((double)dyh2[j] - wd * m2[j] - wd * ((double)f.z2h[j] * m2[DN_H2 + j]));
 #pragma unroll
         for (int c = 0; c < DN_H1; ++c) {
             float a = 0.f;
@@ -348,8 +389,8 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
             for (int j = 0; j < DN_H2; ++j) a += prm[DN_W2 + j * DN_H1 + c] * dz2[j];
             const float dyh1 = f.h1[c] > 0.f ? a : 0.f;
             const float x1h = prm[DN_W1 + c] * f.xh * inv1[c];          // normalised layer-1 pre-activation
-            const float dz1 = prm[DN_G1 + c] * inv1[c] * (float)((double)dyh1 - m1[c] - (double)x1h * m1[DN_H1 + c]);
-            acc[c] += dz1 * x[t];
+            const float dz1 = prm[DN_G1 + c] * inv1[c] * (float)((double)dyh1 - wd * m1[c] - wd * ((double)x1h * m1[DN_H1 + c]));
+            acc[c] += dz1 * xv;
             acc[DN_H1 + c] += dz1;
         }
     }
@@ -396,43 +437,87 @@ PDA_API int64_t pda_densitynet_scratch_bytes(void) {
     return (int64_t)4 * pda::DN_BLOCKS * pda::DN_MAXP * (int64_t)sizeof(double) + pda::DN_NSTAT * (int64_t)sizeof(float);
 }
 
-PDA_API int pda_densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
-                               float* running_var1, float* running_mean2, float* running_var2, float* running_mean3,
-                               float* running_var3, int64_t n, float eps, float momentum, pda_stream_t stream) {
-    PDA_REQUIRE(n >= 1, "pda_densitynet_fwd: n = %lld", (long long)n);
-    PDA_REQUIRE(x && params && y && stats && scratch, "pda_densitynet_fwd: null pointer");
-    const int grid = pda::dn_grid(n);
+namespace pda {
+
+static int densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
+                          float* running_var1, float* running_mean2, float* running_var2, float* running_mean3, float* running_var3,
+                          int64_t n, float eps, float momentum, hipStream_t st, const DnRows& R, const char* what) {
+    PDA_REQUIRE(n >= 1, "%s: n = %lld", what, (long long)n);
+    PDA_REQUIRE(x && params && y && stats && scratch, "%s: null pointer", what);
+    const int grid = dn_grid(n);      // unique rows: the count is on the device; blocks behind it add zeros
     double* pa = (double*)scratch;
-    double* pb = pa + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
-    hipStream_t st = (hipStream_t)stream;
-#define PDA_DN_FWD(P, IN, OUT) hipLaunchKernelGGL(pda::densitynet_fwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, params, stats, IN, OUT, y, n, eps, \
-                                                  momentum, running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3, grid)
+    double* pb = pa + (size_t)DN_BLOCKS * DN_MAXP;
+#define PDA_DN_FWD(P, IN, OUT) hipLaunchKernelGGL(densitynet_fwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, params, stats, IN, OUT, y, n, eps, \
+                                                  momentum, running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3, grid, R)
     PDA_DN_FWD(1, (double*)nullptr, pa);
     PDA_DN_FWD(2, pa, pb);
     PDA_DN_FWD(3, pb, pa);
     PDA_DN_FWD(4, pa, (double*)nullptr);
 #undef PDA_DN_FWD
-    return pda::check_launch("pda_densitynet_fwd");
+    return check_launch(what);
 }
 
-PDA_API int pda_densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
-                               void* scratch, int64_t n, float eps, pda_stream_t stream) {
-    PDA_REQUIRE(n >= 1, "pda_densitynet_bwd: n = %lld", (long long)n);
-    PDA_REQUIRE(x && grad_y && params && stats && grad_params && scratch, "pda_densitynet_bwd: null pointer");
-    const int grid = pda::dn_grid(n);
+static int densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
+                          void* scratch, int64_t n, float eps, hipStream_t st, const DnRows& R, const char* what) {
+    PDA_REQUIRE(n >= 1, "%s: n = %lld", what, (long long)n);
+    PDA_REQUIRE(x && grad_y && params && stats && grad_params && scratch, "%s: null pointer", what);
+    const int grid = dn_grid(n);
     double* p1 = (double*)scratch;
-    double* p2 = p1 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
-    double* p3 = p2 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
-    double* p4 = p3 + (size_t)pda::DN_BLOCKS * pda::DN_MAXP;
-    hipStream_t st = (hipStream_t)stream;
-#define PDA_DN_BWD(P, OUT) hipLaunchKernelGGL(pda::densitynet_bwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, grad_y, params, stats, p1, p2, p3, OUT, n, eps, grid)
+    double* p2 = p1 + (size_t)DN_BLOCKS * DN_MAXP;
+    double* p3 = p2 + (size_t)DN_BLOCKS * DN_MAXP;
+    double* p4 = p3 + (size_t)DN_BLOCKS * DN_MAXP;
+#define PDA_DN_BWD(P, OUT) hipLaunchKernelGGL(densitynet_bwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, grad_y, params, stats, p1, p2, p3, OUT, n, eps, grid, R)
     PDA_DN_BWD(1, p1);
     PDA_DN_BWD(2, p2);
     PDA_DN_BWD(3, p3);
     PDA_DN_BWD(4, p4);
 #undef PDA_DN_BWD
-    hipLaunchKernelGGL(pda::densitynet_grads_kernel, dim3(1), dim3(256), 0, st, p1, p2, p3, p4, grad_params, grid);
-    return pda::check_launch("pda_densitynet_bwd");
+    hipLaunchKernelGGL(densitynet_grads_kernel, dim3(1), dim3(256), 0, st, p1, p2, p3, p4, grad_params, grid);
+    return check_launch(what);
+}
+
+static int dn_unique_rows(const int32_t* rowmap, const float* row_weight, const int32_t* n_unique, int64_t n, int nsample, DnRows& R,
+                          const char* what) {
+    PDA_REQUIRE(rowmap && row_weight && n_unique, "%s: null pointer", what);
+    PDA_REQUIRE(nsample >= 1 && n % nsample == 0, "%s: n = %lld is not groups x nsample = %d", what, (long long)n, nsample);
+    R = DnRows{rowmap, row_weight, n_unique, nsample};
+    return PDA_OK;
+}
+
+}  // namespace pda
+
+PDA_API int pda_densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
+                               float* running_var1, float* running_mean2, float* running_var2, float* running_mean3,
+                               float* running_var3, int64_t n, float eps, float momentum, pda_stream_t stream) {
+    return pda::densitynet_fwd(x, params, y, stats, scratch, running_mean1, running_var1, running_mean2, running_var2, running_mean3,
+                               running_var3, n, eps, momentum, (hipStream_t)stream, pda::DnRows{nullptr, nullptr, nullptr, 1},
+                               "pda_densitynet_fwd");
+}
+
+PDA_API int pda_densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
+                               void* scratch, int64_t n, float eps, pda_stream_t stream) {
+    return pda::densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps, (hipStream_t)stream,
+                               pda::DnRows{nullptr, nullptr, nullptr, 1}, "pda_densitynet_bwd");
+}
+
+PDA_API int pda_densitynet_fwd_unique(const float* x, const float* params, float* y, float* stats, void* scratch,
+                                      float* running_mean1, float* running_var1, float* running_mean2, float* running_var2,
+                                      float* running_mean3, float* running_var3, int64_t n, const int32_t* rowmap,
+                                      const float* row_weight, const int32_t* n_unique, int nsample, float eps, float momentum,
+                                      pda_stream_t stream) {
+    pda::DnRows R;
+    if (int rc = pda::dn_unique_rows(rowmap, row_weight, n_unique, n, nsample, R, "pda_densitynet_fwd_unique")) return rc;
+    return pda::densitynet_fwd(x, params, y, stats, scratch, running_mean1, running_var1, running_mean2, running_var2, running_mean3,
+                               running_var3, n, eps, momentum, (hipStream_t)stream, R, "pda_densitynet_fwd_unique");
+}
+
+PDA_API int pda_densitynet_bwd_unique(const float* x, const float* grad_y, const float* params, const float* stats,
+                                      float* grad_params, void* scratch, int64_t n, const int32_t* rowmap, const float* row_weight,
+                                      const int32_t* n_unique, int nsample, float eps, pda_stream_t stream) {
+    pda::DnRows R;
+    if (int rc = pda::dn_unique_rows(rowmap, row_weight, n_unique, n, nsample, R, "pda_densitynet_bwd_unique")) return rc;
+    return pda::densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps, (hipStream_t)stream, R,
+                               "pda_densitynet_bwd_unique");
 }
 
 // ---- PDA grouper geometry -------------------------------------------------------------------------------

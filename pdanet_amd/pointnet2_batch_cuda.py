@@ -552,6 +552,33 @@ def densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps):
     return 1
 
 
+def _unique_rows(rowmap, roww, off, groups, n, nsample):
+    """(rowmap, row_weight, n_unique) pointers of a plan (pda_ragged_plan): n_unique = &off[groups], on the device."""
+    assert groups * nsample == n and off.numel() >= groups + 1 and off.dtype == I32 and off.is_contiguous()
+    _numel_ok(rowmap, 0, "rowmap"); _numel_ok(roww, 0, "row_weight")
+    return _chk(rowmap, "rowmap", I32), _chk(roww, "row_weight", F32), off.data_ptr() + 4 * groups
+
+
+def densitynet_fwd_unique(x, params, y, stats, scratch, running, n, rowmap, roww, off, groups, nsample, eps, momentum):
+    """densitynet_fwd on the distinct slots of padded neighbour lists (include/pda_train.h): the same y in every slot."""
+    _numel_ok(x, n, "x"); _numel_ok(y, n, "y")
+    r = [None] * 6 if running is None else [_chk(t, "running", F32) for t in running]
+    _buffers_written(running)
+    rm, rw, nu = _unique_rows(rowmap, roww, off, groups, n, nsample)
+    _call("pda_densitynet_fwd_unique", x, _chk(x, "x", F32), _chk(params, "params", F32), _chk(y, "y", F32), _chk(stats, "stats", F32),
+          _chk(scratch, "scratch", torch.uint8), *r, n, rm, rw, nu, nsample, float(eps), float(momentum))
+    return 1
+
+
+def densitynet_bwd_unique(x, grad_y, params, stats, grad_params, scratch, n, rowmap, roww, off, groups, nsample, eps):
+    _numel_ok(x, n, "x"); _numel_ok(grad_y, n, "grad_y")
+    rm, rw, nu = _unique_rows(rowmap, roww, off, groups, n, nsample)
+    _call("pda_densitynet_bwd_unique", x, _chk(x, "x", F32), _chk(grad_y, "grad_y", F32), _chk(params, "params", F32),
+          _chk(stats, "stats", F32), _chk(grad_params, "grad_params", F32), _chk(scratch, "scratch", torch.uint8), n, rm, rw, nu,
+          nsample, float(eps))
+    return 1
+
+
 def pda_geometry(xyz, new_xyz, idx, rppe, dscale, b, n, m, nsample, radius):
     """MI355X extension: relative-position input and normalised gaussian density of a PDA scale (csrc/densitynet.hip)."""
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(idx, b * m * nsample, "idx")

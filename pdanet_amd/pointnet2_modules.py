@@ -694,9 +694,11 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         # for on this stream and on the host), otherwise here with ONE host synchronisation for the layer
         plans = [None] * len(self.groupers)
         pending = None
+        plan_parts = None            # the plans' device halves (cnt, off, rowmap, roww): usable before any count is read
         if prequery is not None:
             idxs = prequery['idxs']
             if prequery['parts'] is not None and self.ragged_capable(features):
+                plan_parts = prequery['parts']
                 plans = pointnet2_utils.ragged_plans_from(prequery['parts'], prequery['totals'].tolist())
         else:
             idxs = self._ball_queries(xyz, new_xyz)
@@ -708,6 +710,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 # blocking read left the device with an empty queue behind the plan kernel and ~100 small launches to
                 # wait for (1.3 ms idle per step, tools/step_gaps.py).
                 parts, totals = pointnet2_utils.ragged_plan_parts(idxs)
+                plan_parts = parts
                 pinned = torch.empty((len(parts),), dtype=torch.int32, pin_memory=True)
                 pinned.copy_(totals, non_blocking=True)
                 ev = torch.cuda.Event()
@@ -742,7 +745,10 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
             dn = self.point_density[i].densitynet
             if pointnet2_utils.DensityNetFused.supported(dscale, dn):
-                dscale = pointnet2_utils.densitynet(dn, dscale)            # 4 + 5 launches instead of ~45
+                # 4 + 5 launches instead of ~45; with a plan on the device (its token count not read yet), over the
+                # distinct slots only -- dscale of a repeat slot equals its group's slot 0 (the same neighbour)
+                part = plan_parts[i] if (plan_parts is not None and fused_geo) else None
+                dscale = pointnet2_utils.densitynet(dn, dscale, part)
             else:
                 for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
                     if _can_fold(conv, bn):

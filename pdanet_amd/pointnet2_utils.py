@@ -407,7 +407,11 @@ class DensityNetFused(Function):
                 and not torch.is_autocast_enabled() and x.numel() > 0)
 
     @staticmethod
-    def forward(ctx, x, eps, momentum, running, *params):
+    def forward(ctx, x, eps, momentum, running, part, *params):
+        """part: None, or the device half of the scale's unique-token plan (ragged_plan_parts: cnt, off, rowmap, roww, groups,
+        ns) -- x (groups, ns) then holds ball_query's repeats of each group's first neighbour behind its distinct slots, and
+        only the distinct slots are evaluated (csrc/densitynet.hip, DnRows): same y in every slot, same statistics and
+        gradients, 5-10 x fewer tokens walked by the nine passes.  No host read: the count stays on the device."""
         x = x.contiguous()
         n = x.numel()
         packed = torch.cat([p.reshape(-1) for p in params])
@@ -416,28 +420,41 @@ class DensityNetFused(Function):
         y = torch.empty_like(x)
         stats = torch.empty((46,), dtype=torch.float32, device=x.device)
         scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
-        pointnet2.densitynet_fwd(x, packed, y, stats, scratch, running, n, eps, momentum)
-        ctx.save_for_backward(x, packed, stats)
+        if part is None:
+            pointnet2.densitynet_fwd(x, packed, y, stats, scratch, running, n, eps, momentum)
+            ctx.save_for_backward(x, packed, stats)
+        else:
+            _, off, rowmap, roww, G, ns = part
+            pointnet2.densitynet_fwd_unique(x, packed, y, stats, scratch, running, n, rowmap, roww, off, G, ns, eps, momentum)
+            ctx.save_for_backward(x, packed, stats, off, rowmap, roww)
+            ctx.groups, ctx.ns = G, ns
+        ctx.unique = part is not None
         ctx.eps = eps
         ctx.shapes = [p.shape for p in params]
         return y
 
     @staticmethod
     def backward(ctx, grad_y):
-        x, packed, stats = ctx.saved_tensors
+        x, packed, stats = ctx.saved_tensors[:3]
         nparam, nscratch = pointnet2.densitynet_sizes()
         grads = torch.empty((nparam,), dtype=torch.float32, device=x.device)
         scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
-        pointnet2.densitynet_bwd(x, grad_y.contiguous(), packed, stats, grads, scratch, x.numel(), ctx.eps)
+        if ctx.unique:
+            off, rowmap, roww = ctx.saved_tensors[3:]
+            pointnet2.densitynet_bwd_unique(x, grad_y.contiguous(), packed, stats, grads, scratch, x.numel(), rowmap, roww, off,
+                                            ctx.groups, ctx.ns, ctx.eps)
+        else:
+            pointnet2.densitynet_bwd(x, grad_y.contiguous(), packed, stats, grads, scratch, x.numel(), ctx.eps)
         pieces = torch.split(grads, DensityNetFused.SPLITS)
-        return (None, None, None, None) + tuple(g.view(s) for g, s in zip(pieces, ctx.shapes))
+        return (None, None, None, None, None) + tuple(g.view(s) for g, s in zip(pieces, ctx.shapes))
 
 
 FUSED_DENSITYNET = True
+DENSITYNET_UNIQUE = os.environ.get("PDA_DENSITYNET_UNIQUE", "1") != "0"     # distinct slots only where a plan exists
 
 
-def densitynet(dn, x):
-    """DensityNet module `dn` (pointnet2_modules.DensityNet) on x (..., 1) in training mode."""
+def densitynet(dn, x, part=None):
+    """DensityNet module `dn` (pointnet2_modules.DensityNet) on x (..., 1) in training mode.  part: see DensityNetFused."""
     convs, bns = dn.mlp_convs, dn.mlp_bns
     running = None
     if all(b.track_running_stats for b in bns):
@@ -447,7 +464,7 @@ def densitynet(dn, x):
     params = []
     for c, b in zip(convs, bns):
         params += [c.weight, c.bias, b.weight, b.bias]
-    return DensityNetFused.apply(x, bns[0].eps, bns[0].momentum, running, *params)
+    return DensityNetFused.apply(x, bns[0].eps, bns[0].momentum, running, part if DENSITYNET_UNIQUE else None, *params)
 
 
 class LinearLongTokens(Function):

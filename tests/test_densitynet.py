@@ -1,6 +1,11 @@
 """csrc/densitynet.hip against the torch module (float64): forward, running statistics, parameter gradients."""
+import os
+import sys
+
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -38,6 +43,51 @@ def test_fused_densitynet_matches_module(shape):
         assert torch.allclose(b1.running_mean.double(), b2.running_mean, atol=1e-6)
         assert torch.allclose(b1.running_var.double(), b2.running_var, atol=1e-6, rtol=1e-5)
         assert int(b1.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("G,ns,p_single,p_full,sparse_grad", [(7, 8, 0.3, 0.1, True), (1000, 16, 0.7, 0.05, True),
+                                                               (8192, 32, 0.3, 0.1, True), (4099, 32, 0.0, 1.0, True),
+                                                               (1500, 16, 1.0, 0.0, False), (8192, 32, 0.5, 0.1, False)])
+def test_densitynet_on_distinct_slots_equals_dense(G, ns, p_single, p_full, sparse_grad):
+    """pda_densitynet_fwd_unique / _bwd_unique (the passes walk only the distinct slots of padded neighbour lists, slot 0
+    weighted by its multiplicity) against the dense passes on the same (groups, ns) tensor whose repeat slots hold slot 0's
+    value: y in EVERY slot, running statistics, parameter gradients -- with the gradient the ragged consumer leaves (zero
+    on the repeats) and with a gradient on every slot (a dense consumer: the unique backward sums a token's copies)."""
+    import numpy as np
+    from pdanet_amd import pointnet2_modules as pm, pointnet2_utils as pu
+    from test_ragged_tokens import padded_idx
+    rng = np.random.default_rng(G + ns)
+    idx, cnt = padded_idx(G, ns, 5000, rng, p_single, p_full, empty_rows=min(2, G - 1) if p_full < 1.0 else 0)
+    idx_t = torch.from_numpy(idx).cuda().view(1, G, ns)
+    parts, _ = pu.ragged_plan_parts([idx_t])
+    torch.manual_seed(G)
+    # x per DISTINCT neighbour; a repeat slot holds what slot 0 holds (the same neighbour of the same centre)
+    val = torch.rand(5000, device="cuda")
+    x = val[idx_t.long()].view(1, G, ns, 1).contiguous()
+    models = []
+    for _ in range(2):
+        torch.manual_seed(3)
+        dn = pm.DensityNet().cuda().train()
+        with torch.no_grad():
+            for b in dn.mlp_bns:
+                b.weight.uniform_(0.5, 1.5); b.bias.normal_(0, 0.3); b.running_mean.normal_(); b.running_var.uniform_(0.5, 2)
+        models.append(dn)
+    y_u = pu.densitynet(models[0], x, parts[0])
+    y_d = pu.densitynet(models[1], x, None)
+    assert (y_u - y_d).abs().max().item() < 2e-6
+    go = torch.randn_like(y_d)
+    if sparse_grad:
+        slot = torch.arange(ns, device="cuda").view(1, 1, ns, 1)
+        go = torch.where(slot < torch.from_numpy(cnt).cuda().view(1, G, 1, 1), go, torch.zeros_like(go))
+    g_u = torch.autograd.grad(y_u, list(models[0].parameters()), go)
+    g_d = torch.autograd.grad(y_d, list(models[1].parameters()), go)
+    ntok = x.numel()
+    for (n, _), a, b in zip(models[0].named_parameters(), g_u, g_d):
+        tol = 3e-5 * max(1.0, b.abs().max().item()) + (4e-8 * ntok if "mlp_convs" in n else 0.0)   # see the test above
+        assert (a - b).abs().max().item() < tol, n
+    for b1, b2 in zip(models[0].mlp_bns, models[1].mlp_bns):
+        assert torch.allclose(b1.running_mean, b2.running_mean, atol=1e-6)
+        assert torch.allclose(b1.running_var, b2.running_var, atol=1e-6, rtol=1e-5)
 
 
 @pytest.mark.parametrize("B,N,M,ns,r", [(1, 50, 7, 16, 0.8), (2, 4096, 1000, 32, 1.6), (3, 300, 129, 8, 4.8)])

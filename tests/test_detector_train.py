@@ -22,7 +22,14 @@ def _setup(cfg, dataset, B=2, N=4096):
 # Iteration-0 loss of the setup above, identical to the last bit on four different MI355X boxes in rounds 1-2
 # (GPUTEST_r01.json, gpurun_out/hang.log, gpurun_out/r02_trace.log): the forward pass has no float atomics and
 # is deterministic.  rel=1e-4 leaves room for a different library-GEMM heuristic on another ROCm build.
-PINNED_FIRST_LOSS = {"once": 29.190820693969727, "kitti": 161.17782592773438}
+# Re-pinned late in round 3 (were 29.190820693969727 / 161.17782592773438): DensityNet now adds its batch statistics
+# over the distinct slots with multiplicities (csrc/densitynet.hip, DnRows) -- another order of the same float sums,
+# 3e-6 on its outputs -- and on this UNTRAINED model (all confidence scores within 1e-3 of each other) that moves
+# near-tied entries across the top-k boundary of the ctr-aware sampling of layer 2: other points, another loss.
+# test_densitynet_on_distinct_slots_moves_only_near_ties_of_the_top_k below holds the old numbers for the dense form
+# and checks that nothing but such ties moves.
+PINNED_FIRST_LOSS = {"once": 29.138832092285156, "kitti": 161.17782592773438}
+PINNED_FIRST_LOSS_DENSE_DENSITYNET = {"once": 29.190820693969727, "kitti": 161.17782592773438}
 CASES = [("once_pda_ssd.yaml", "once"), ("kitti_pda_ssd.yaml", "kitti")]
 
 
@@ -33,6 +40,46 @@ def _iteration(model, opt, sched, bd, it):
     ret, tb, _ = model(bd())
     ret['loss'].backward()
     return ret, tb
+
+
+@pytest.mark.parametrize("cfg,dataset", CASES)
+def test_densitynet_on_distinct_slots_moves_only_near_ties_of_the_top_k(cfg, dataset):
+    """Iteration 0 with DensityNet on the distinct slots (default) against the dense form (round 1-2's arithmetic): the
+    dense form still gives the loss pinned in rounds 1-2; the first PDA layer's outputs agree to float re-association
+    noise; and where layer 2's ctr-aware top-k (pointnet2_modules.py:1541-1546 of the reference: torch.topk over the
+    sigmoid of the largest class score) picks other points, every point that entered or left sits within that noise of
+    the k-th score."""
+    from pdanet_amd import pointnet2_utils as pu
+    runs = {}
+    try:
+        for unique in (False, True):
+            pu.DENSITYNET_UNIQUE = unique
+            model, opt, sched, bd = _setup(cfg, dataset)
+            got = {}
+            mods = model.backbone_3d.SA_modules
+            hooks = [mods[1].register_forward_hook(lambda m, i, o: got.update(l1=[t.detach().clone() for t in o[:3]])),
+                     mods[2].register_forward_hook(lambda m, i, o: got.update(idx2=o[3].detach().clone()))]
+            ret, _ = _iteration(model, opt, sched, bd, 0)
+            for h in hooks:
+                h.remove()
+            runs[unique] = (float(ret['loss'].detach()), got)
+    finally:
+        pu.DENSITYNET_UNIQUE = True
+    assert runs[False][0] == pytest.approx(PINNED_FIRST_LOSS_DENSE_DENSITYNET[dataset], rel=1e-4)
+    assert runs[True][0] == pytest.approx(runs[False][0], rel=2e-2)
+    (xyz_d, feat_d, cls_d), (xyz_u, feat_u, cls_u) = runs[False][1]['l1'], runs[True][1]['l1']
+    assert torch.equal(xyz_d, xyz_u)
+    assert (feat_d - feat_u).abs().max().item() < 5e-5 and (cls_d - cls_u).abs().max().item() < 2e-5
+    score = torch.sigmoid(cls_d.max(dim=-1)[0])                              # (B, M) as sample_points ranks them
+    idx_d, idx_u = runs[False][1]['idx2'].long(), runs[True][1]['idx2'].long()
+    k = idx_d.shape[1]
+    kth = torch.topk(score, k, dim=-1)[0][:, -1]
+    for b in range(score.shape[0]):
+        a, c = set(idx_d[b].tolist()), set(idx_u[b].tolist())
+        moved = sorted(a ^ c)
+        if moved:
+            gap = (score[b, moved] - kth[b]).abs().max().item()
+            assert gap < 2e-5, (b, len(moved), gap)
 
 
 @pytest.mark.parametrize("cfg,dataset", CASES)
