@@ -199,7 +199,9 @@ int pda_bn_relu_bwd_weighted(const float *x, const float *grad_y, const float *g
  *   a compact row's gradient is the sum over its copies).
  * pda_assemble_tokens_ragged(_grad): pda_assemble_tokens writing / reading compact rows (out (U, 4C)); the grid
  *   covers max_tokens >= U rows and reads U on the device.  The gradient entry writes the DENSE grad_rppe /
- *   grad_dscale (zero at the repeat slots) and grad_glob, and ADDS into grad_feats (zero-filled by the caller).
+ *   grad_dscale (zero at the repeat slots) and grad_glob, and ADDS into grad_feats (zero-filled by the caller);
+ *   with rowmap (and max_tokens >= U) its per-token part runs over (token, column) threads, with rowmap NULL one
+ *   thread walks the tokens of a centre (same results; grad_feats is a float-atomic sum either way).
  * pda_add_max_pool_ragged / pda_max_pool_scatter_ragged: the add + max-pool tail on compact rows; arg = slot.
  * pda_group_attention_ragged_fwd/bwd (include/pda_pointnet2.h layout with compact rows): qkv (U, 3, H, hd),
  *   out / grad_out (U, H * hd), lse (groups, H, seq).  tokens = U (the caller has read it to size qkv): one wave
@@ -212,9 +214,10 @@ int pda_assemble_tokens_ragged(const float *rppe, const float *dscale, const flo
                                int64_t max_tokens, int b, int n, int m, int nsample, int c, int rppe_compact,
                                pda_stream_t stream);
 int pda_assemble_tokens_ragged_grad(const float *grad_out, const float *dscale, const float *feats,
-                                    const int32_t *idx, const int32_t *cnt, const int32_t *off, float *grad_rppe,
-                                    float *grad_dscale, float *grad_feats, float *grad_glob, int b, int n, int m,
-                                    int nsample, int c, int rppe_compact, pda_stream_t stream);
+                                    const int32_t *idx, const int32_t *cnt, const int32_t *off, const int32_t *rowmap,
+                                    float *grad_rppe, float *grad_dscale, float *grad_feats, float *grad_glob,
+                                    int64_t max_tokens, int b, int n, int m, int nsample, int c, int rppe_compact,
+                                    pda_stream_t stream);
 int pda_add_max_pool_ragged(const float *a, const float *b, const int32_t *cnt, const int32_t *off, float *out,
                             uint8_t *arg, int64_t groups, int d, pda_stream_t stream);
 int pda_max_pool_scatter_ragged(const float *grad_out, const uint8_t *arg, const int32_t *rowmap,

@@ -98,7 +98,7 @@ SIGNATURES = {
     "pda_max_pool_scatter_bf16": [_vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _vp],
     "pda_ragged_plan": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],
     "pda_assemble_tokens_ragged": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _i, _i, _i, _vp],
-    "pda_assemble_tokens_ragged_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "pda_assemble_tokens_ragged_grad": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _i, _i, _i, _i, _i, _vp],
     "pda_bn_relu_fwd_weighted": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _f, _f, _vp, ctypes.c_int64, _vp],
     "pda_bn_relu_bwd_weighted": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp, ctypes.c_int64, _vp],
     "pda_add_max_pool_ragged": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _i, _vp],

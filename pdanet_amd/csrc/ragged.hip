@@ -148,6 +148,70 @@ __global__ __launch_bounds__(256) void assemble_ragged_bwd_kernel(const float* _
     if (live) reinterpret_cast<float4*>(d_glob)[bm * c4 + c] = acc_g;
 }
 
+// The same backward with the per-token work spread over (compact token, column) threads -- the form above gives a thread the
+// 1..ns tokens of ONE centre, a chain of dependent loads per token with two waves per SIMD on the ONCE scales (0.16 ms on
+// the 63 511-token scale) -- and the per-centre part (d_glob, the zeros on the repeat slots) left to (centre, column) threads.
+// d_rppe / d_dscale / d_glob are the same values bit for bit; d_feats is a float-atomic sum either way.
+template <int c4>
+__global__ __launch_bounds__(256) void assemble_ragged_bwd_token_kernel(const float* __restrict__ dx, const float* __restrict__ dscale,
+                                                                        const float* __restrict__ feats, const int* __restrict__ idx,
+                                                                        const int32_t* __restrict__ rowmap, const int32_t* __restrict__ off,
+                                                                        float* __restrict__ d_rppe, float* __restrict__ d_dscale,
+                                                                        float* __restrict__ d_feats, int n, int m, int ns, int groups,
+                                                                        int rppe_compact) {
+    const int64_t total = (int64_t)off[groups] * c4;             // U is read on the device: the grid covers a host bound
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (compact token, column)
+    const bool live = e < total;
+    const int64_t ec = live ? e : (total > 0 ? total - 1 : 0);   // dead lanes shadow the last element (shuffles stay uniform)
+    if (total == 0) return;
+    const int c = (int)(ec % c4);
+    const int64_t u = ec / c4;
+    const int64_t tok = rowmap[u];
+    const int64_t b = (tok / ns) / m;
+    const float4* g4 = reinterpret_cast<const float4*>(dx) + (size_t)u * 4 * c4 + c;
+    const float4 g_r = g4[0], g_fd = g4[c4], g_f = g4[2 * c4];
+    const int row = idx[tok];
+    const float4 f = (reinterpret_cast<const float4*>(feats) + (size_t)b * n * c4 + c)[(size_t)row * c4];
+    const float d = dscale[tok];
+    float part = (g_fd.x * f.x + g_fd.y * f.y) + (g_fd.z * f.z + g_fd.w * f.w);
+#pragma unroll
+    for (int o = c4 >> 1; o >= 1; o >>= 1) part += __shfl_xor(part, o);
+    if (!live) return;
+    reinterpret_cast<float4*>(d_rppe)[(size_t)(rppe_compact ? u : tok) * c4 + c] = g_r;
+    if (c == 0) d_dscale[tok] = part;
+    float* df = d_feats + (((size_t)b * n + row) * c4 + c) * 4;
+    atomicAdd(df + 0, g_fd.x * d + g_f.x); atomicAdd(df + 1, g_fd.y * d + g_f.y);
+    atomicAdd(df + 2, g_fd.z * d + g_f.z); atomicAdd(df + 3, g_fd.w * d + g_f.w);
+}
+
+__global__ __launch_bounds__(256) void assemble_ragged_bwd_group_kernel(const float* __restrict__ dx, const int32_t* __restrict__ cnt,
+                                                                        const int32_t* __restrict__ off, float* __restrict__ d_rppe,
+                                                                        float* __restrict__ d_dscale, float* __restrict__ d_glob, int c4,
+                                                                        int ns, int64_t total, int rppe_compact) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;   // (centre, column)
+    if (e >= total) return;
+    const int c = (int)(e % c4);
+    const int64_t bm = e / c4;
+    const int n_tok = cnt[bm];
+    const float4* g4 = reinterpret_cast<const float4*>(dx) + (size_t)off[bm] * 4 * c4 + 3 * c4 + c;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int t = 0;
+    for (; t + 4 <= n_tok; t += 4) {                              // four independent loads in flight; the sum keeps the token order
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = g4[(size_t)(t + q) * 4 * c4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+    }
+    for (; t < n_tok; ++t) { const float4 v = g4[(size_t)t * 4 * c4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    reinterpret_cast<float4*>(d_glob)[bm * c4 + c] = acc;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (t = n_tok; t < ns; ++t) {                                // the repeats' slots of the dense gradients
+        if (!rppe_compact) reinterpret_cast<float4*>(d_rppe)[(size_t)(bm * ns + t) * c4 + c] = zero;
+        if (c == 0) d_dscale[bm * ns + t] = 0.f;
+    }
+}
+
 // out (G, D) = max over the cnt tokens of a group of a + b (compact rows), arg = slot of the first maximum.
 __global__ __launch_bounds__(256) void add_max_pool_ragged_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                                   const int32_t* __restrict__ cnt, const int32_t* __restrict__ off,
@@ -228,10 +292,10 @@ PDA_API int pda_assemble_tokens_ragged(const float* rppe, const float* dscale, c
 }
 
 PDA_API int pda_assemble_tokens_ragged_grad(const float* grad_out, const float* dscale, const float* feats, const int32_t* idx,
-                                            const int32_t* cnt, const int32_t* off, float* grad_rppe, float* grad_dscale,
-                                            float* grad_feats, float* grad_glob, int b, int n, int m, int nsample, int c,
-                                            int rppe_compact, pda_stream_t stream) {
-    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && pda::ragged_c_ok(c),
+                                            const int32_t* cnt, const int32_t* off, const int32_t* rowmap, float* grad_rppe,
+                                            float* grad_dscale, float* grad_feats, float* grad_glob, int64_t max_tokens, int b, int n,
+                                            int m, int nsample, int c, int rppe_compact, pda_stream_t stream) {
+    PDA_REQUIRE(b >= 0 && n >= 1 && m >= 0 && nsample >= 1 && max_tokens >= 0 && pda::ragged_c_ok(c),
                 "pda_assemble_tokens_ragged_grad: b=%d n=%d m=%d nsample=%d C=%d", b, n, m, nsample, c);
     const int64_t centre_cols = (int64_t)b * m * (c / 4);
     if (centre_cols == 0) return PDA_OK;
@@ -240,6 +304,21 @@ PDA_API int pda_assemble_tokens_ragged_grad(const float* grad_out, const float* 
     PDA_REQUIRE((((uintptr_t)grad_out | (uintptr_t)feats | (uintptr_t)grad_rppe | (uintptr_t)grad_glob) & 15) == 0,
                 "pda_assemble_tokens_ragged_grad: alignment");
     const dim3 grid((unsigned)pda::divup64(centre_cols, 256)), block(256);
+    if (rowmap) {
+        // per-token work over (compact token, column) threads, per-centre work over (centre, column) threads
+        const int64_t tok_cols = max_tokens * (c / 4);
+        if (tok_cols > 0) {
+            const dim3 tgrid((unsigned)pda::divup64(tok_cols, 256));
+#define PDA_ASM_TOK(C4)                                                                                                               \
+    case C4: hipLaunchKernelGGL(pda::assemble_ragged_bwd_token_kernel<C4>, tgrid, block, 0, (hipStream_t)stream, grad_out, dscale, feats, \
+                                idx, rowmap, off, grad_rppe, grad_dscale, grad_feats, n, m, nsample, b * m, rppe_compact); break
+            switch (c / 4) { PDA_ASM_TOK(4); PDA_ASM_TOK(8); PDA_ASM_TOK(16); PDA_ASM_TOK(32); PDA_ASM_TOK(64); }
+#undef PDA_ASM_TOK
+        }
+        hipLaunchKernelGGL(pda::assemble_ragged_bwd_group_kernel, grid, block, 0, (hipStream_t)stream, grad_out, cnt, off, grad_rppe,
+                           grad_dscale, grad_glob, c / 4, nsample, centre_cols, rppe_compact);
+        return pda::check_launch("pda_assemble_tokens_ragged_grad");
+    }
 #define PDA_ASM_BWD(C4)                                                                                                          \
     case C4: hipLaunchKernelGGL(pda::assemble_ragged_bwd_kernel<C4>, grid, block, 0, (hipStream_t)stream, grad_out, dscale, feats, idx, \
                                 cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, n, m, nsample, centre_cols, rppe_compact); break

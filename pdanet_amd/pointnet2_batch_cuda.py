@@ -672,14 +672,17 @@ def assemble_tokens_ragged(rppe, dscale, feats, idx, glob, rowmap, off, out, tok
 
 
 def assemble_tokens_ragged_grad(grad_out, dscale, feats, idx, cnt, off, grad_rppe, grad_dscale, grad_feats, grad_glob, tokens, b, n, m, nsample, c,
-                                rppe_compact=False):
+                                rppe_compact=False, rowmap=None):
+    """rowmap (the plan's compact-row -> dense-slot map, >= tokens entries): the per-token part runs token-parallel."""
     t = b * m * nsample
+    if rowmap is not None:
+        _numel_ok(rowmap, tokens, "rowmap")
     _numel_ok(grad_out, tokens * 4 * c, "grad_out"); _numel_ok(grad_rppe, (tokens if rppe_compact else t) * c, "grad_rppe"); _numel_ok(grad_dscale, t, "grad_dscale")
     _numel_ok(grad_feats, b * n * c, "grad_feats"); _numel_ok(grad_glob, b * m * c, "grad_glob"); _numel_ok(cnt, b * m, "cnt"); _numel_ok(off, b * m + 1, "off")
     _call("pda_assemble_tokens_ragged_grad", grad_out, _chk(grad_out, "grad_out", F32), _chk(dscale, "dscale", F32), _chk(feats, "feats", F32),
-          _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), _chk(grad_rppe, "grad_rppe", F32),
-          _chk(grad_dscale, "grad_dscale", F32), _chk(grad_feats, "grad_feats", F32), _chk(grad_glob, "grad_glob", F32), b, n, m, nsample, c,
-          1 if rppe_compact else 0)
+          _chk(idx, "idx", I32), _chk(cnt, "cnt", I32), _chk(off, "off", I32), None if rowmap is None else _chk(rowmap, "rowmap", I32),
+          _chk(grad_rppe, "grad_rppe", F32), _chk(grad_dscale, "grad_dscale", F32), _chk(grad_feats, "grad_feats", F32),
+          _chk(grad_glob, "grad_glob", F32), tokens, b, n, m, nsample, c, 1 if rppe_compact else 0)
     return 1
 
 

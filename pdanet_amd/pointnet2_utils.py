@@ -1431,6 +1431,9 @@ def ragged_plans(idxs):
     return ragged_plans_from(parts, totals.tolist())
 
 
+ASSEMBLE_BWD_TOKEN_PARALLEL = os.environ.get("PDA_ASSEMBLE_BWD_TOKEN_PARALLEL", "1") != "0"
+
+
 class AssembleTokensRagged(Function):
     """AssembleTokens writing only the distinct tokens: x (U, 4C).  rppe is either dense (B,M,ns,C) -- its gradient then
     comes back dense with zeros at the repeat slots -- or compact (U, C) when the position MLP ran on the distinct tokens
@@ -1445,13 +1448,13 @@ class AssembleTokensRagged(Function):
         out = torch.empty((plan.tokens, 4 * C), dtype=torch.float32, device=rppe.device)
         pointnet2.assemble_tokens_ragged(rppe, dscale, feats_pm, idx, glob, plan.rowmap, plan.off, out, plan.tokens, B, N, M, ns, C,
                                          rppe_compact=compact)
-        ctx.save_for_backward(dscale, feats_pm, idx, plan.cnt, plan.off)
+        ctx.save_for_backward(dscale, feats_pm, idx, plan.cnt, plan.off, plan.rowmap)
         ctx.dims = (B, N, M, ns, C, plan.tokens, compact)
         return out
 
     @staticmethod
     def backward(ctx, grad_out):
-        dscale, feats_pm, idx, cnt, off = ctx.saved_tensors
+        dscale, feats_pm, idx, cnt, off, rowmap = ctx.saved_tensors
         B, N, M, ns, C, U, compact = ctx.dims
         dev = grad_out.device
         g_rppe = torch.empty((U, C) if compact else (B, M, ns, C), dtype=torch.float32, device=dev)
@@ -1459,7 +1462,8 @@ class AssembleTokensRagged(Function):
         g_feats = torch.zeros((B, N, C), dtype=torch.float32, device=dev)
         g_glob = torch.empty((B, M, C), dtype=torch.float32, device=dev)
         pointnet2.assemble_tokens_ragged_grad(grad_out.contiguous(), dscale, feats_pm, idx, cnt, off, g_rppe, g_ds, g_feats, g_glob,
-                                              U, B, N, M, ns, C, rppe_compact=compact)
+                                              U, B, N, M, ns, C, rppe_compact=compact,
+                                              rowmap=rowmap if ASSEMBLE_BWD_TOKEN_PARALLEL else None)
         return g_rppe, g_ds, g_feats, None, g_glob, None
 
 

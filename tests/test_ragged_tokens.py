@@ -93,6 +93,38 @@ def test_ragged_attention_equals_dense_attention_on_padded_groups(S, hd, heads, 
     assert torch.isfinite(out_c).all() and torch.isfinite(dq_c).all()
 
 
+@pytest.mark.parametrize("G,S,C,compact", [(203, 16, 64, False), (1000, 32, 128, True), (77, 8, 16, True), (4099, 32, 256, False)])
+def test_assembly_backward_token_parallel_equals_centre_form(G, S, C, compact):
+    """pda_assemble_tokens_ragged_grad with rowmap (per-token work over (token, column) threads + a per-centre kernel) against
+    the form without (one thread walks a centre's tokens): grad_rppe / grad_dscale / grad_glob bit for bit -- including the
+    zeros on the repeat slots --, grad_feats (float atomics in both) to 1e-5."""
+    from pdanet_amd import pointnet2_utils as pu
+    rng = np.random.default_rng(G + S + C)
+    N = 3000
+    idx, cnt = padded_idx(G, S, N, rng)
+    idx_t = torch.from_numpy(idx).cuda().view(1, G, S)
+    (plan,) = pu.ragged_plans([idx_t])
+    torch.manual_seed(C)
+    rppe = torch.randn((plan.tokens, C) if compact else (1, G, S, C), device="cuda", requires_grad=True)
+    dscale = torch.rand(1, G, S, 1, device="cuda", requires_grad=True)
+    feats = torch.randn(1, N, C, device="cuda", requires_grad=True)
+    glob = torch.randn(1, G, C, device="cuda", requires_grad=True)
+    go = torch.randn(plan.tokens, 4 * C, device="cuda")
+    res = {}
+    try:
+        for flag in (True, False):
+            pu.ASSEMBLE_BWD_TOKEN_PARALLEL = flag
+            x = pu.AssembleTokensRagged.apply(rppe, dscale, feats, idx_t, glob, plan)
+            res[flag] = torch.autograd.grad(x, [rppe, dscale, feats, glob], go)
+    finally:
+        pu.ASSEMBLE_BWD_TOKEN_PARALLEL = True
+    for k, name in ((0, "rppe"), (1, "dscale"), (3, "glob")):
+        assert torch.equal(res[True][k], res[False][k]), name
+    assert (res[True][2] - res[False][2]).abs().max().item() <= 1e-5 * max(1.0, res[False][2].abs().max().item())
+    valid = torch.arange(S, device="cuda").view(1, 1, S) < plan.cnt.view(1, G, 1)
+    assert float(res[True][1].view(1, G, S)[~valid].abs().sum()) == 0.0
+
+
 def _pda_layer():
     """ONCE layer 1 in small: C = 64 (encoder width D = 256, the width the fused encoder path is built for)."""
     from pdanet_amd import pointnet2_modules as pm
