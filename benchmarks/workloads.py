@@ -182,7 +182,10 @@ class KernelTimers:
                 "note": "bytes per SURVEY 8(d) (xyz streamed once per 256 centres, per radius); tests = M*N per "
                         "radius = the brute-force count (the cell-list path performs far fewer, so its valu_frac is an "
                         "equivalent rate and may exceed 1); VALU bound = 256 CUs x 64 lanes x 2.4 GHz / 7 instructions per "
-                        "test; the cell-list call is 5 launches (grid, count, scan, scatter, query) timed together"}
+                        "test; the cell-list call is 5 launches (grid, count, scan, scatter, query) timed together.  In the training "
+                        "and inference workloads the layer-0 call is issued on the sampling side stream (beside the D-FPS chain, "
+                        "under the previous iteration) and shares the chip with the main stream's kernels while its events time it: "
+                        "0.21 ms there against 0.13 ms alone (0.054 of HBM, BASELINE.md section 4)"}
 
     def roofline_sa_mlp_train(self):
         """The vanilla-SA group MLPs in training form (forward and input-gradient contractions of ONCE layers 0 and 5; the
