@@ -346,11 +346,10 @@ template <bool BWD, typename TIO, bool RAGGED = false>
 static int launch_group_attention(const TIO* qkv, const TIO* dout, TIO* out, float* lse, TIO* dqkv,
                                   int64_t nb, int s, int h, int hd, hipStream_t stream, const char* what,
                                   const int32_t* cnt = nullptr, const int32_t* off = nullptr, int64_t tokens = 0) {
-    PDA_REQUIRE(nb >= 0 && h >= 1, "%s: bad size", what);
+    PDA_REQUIRE(nb >= 0 && h >= 1 && s >= 1 && s <= 32 && tokens >= 0, "%s: bad size", what);
     if (nb == 0) return PDA_OK;
     PDA_REQUIRE(qkv && lse && (BWD ? (dout && dqkv) : (out != nullptr)), "%s: null pointer", what);
     PDA_REQUIRE(!RAGGED || (cnt && off), "%s: null pointer", what);
-    PDA_REQUIRE(s >= 1 && s <= 32 && tokens >= 0, "%s: bad size", what);
     int G = 32 / s;                                           // groups per wave (group_attention_kernel)
     if (RAGGED) {
         const int64_t mean = std::max<int64_t>(1, std::min<int64_t>(s, divup64(tokens, nb)));

@@ -68,6 +68,24 @@ def test_argument_validation_without_gpu(lib):
     assert lib.pda_gemm_split_bn(None, None, None, 4096, 256, 256, None, None, None, 0, None, None) == 1 and b"null" in lib.pda_last_error()
     assert lib.pda_linear_wgrad_bn(None, None, None, None, None, 65536, 256, 256, None, None, None, None) == 1
     assert lib.pda_bn_finalize_fwd(None, 0, 64, 100, ctypes.c_float(1e-5), ctypes.c_float(0.1), None, None, None, None) == 1
+    # the entries of ABI 20: sizes are checked before any pointer is used
+    i64 = ctypes.c_int64
+    assert lib.pda_group_attention_ragged_fwd(None, None, None, None, None, i64(0), i64(0), 32, 4, 64, None) == 0      # no groups
+    assert lib.pda_group_attention_ragged_fwd(None, None, None, None, None, i64(-1), i64(8), 32, 4, 64, None) == 1
+    assert lib.pda_group_attention_ragged_fwd(None, None, None, None, None, i64(8), i64(8), 33, 4, 64, None) == 1 and b"bad size" in lib.pda_last_error()
+    f = ctypes.c_float
+    assert lib.pda_densitynet_fwd_unique(None, None, None, None, None, None, None, None, None, None, None, i64(100), None, None, None, 16,
+                                         f(1e-5), f(0.1), None) == 1 and b"null" in lib.pda_last_error()
+    one = (ctypes.c_int32 * 1)(0)
+    onef = (ctypes.c_float * 1)(0)
+    assert lib.pda_densitynet_fwd_unique(None, None, None, None, None, None, None, None, None, None, None, i64(100), one, onef, one, 16,
+                                         f(1e-5), f(0.1), None) == 1 and b"groups x nsample" in lib.pda_last_error()
+    assert lib.pda_densitynet_bwd_unique(None, None, None, None, None, None, i64(96), one, onef, one, 16, f(1e-5), None) == 1 \
+        and b"null" in lib.pda_last_error()
+    assert lib.pda_assemble_tokens_ragged_grad(None, None, None, None, None, None, None, None, None, None, None, i64(-1), 1, 8, 8, 16, 64, 0,
+                                               None) == 1
+    assert lib.pda_assemble_tokens_ragged_grad(None, None, None, None, None, None, None, None, None, None, None, i64(0), 1, 8, 0, 16, 64, 0,
+                                               None) == 0          # no centres
     # empty problems are PDA_OK and touch nothing
     assert lib.pda_ball_query(None, None, None, 0, 8, 8, ctypes.c_float(1.0), 4, None) == 0
     assert lib.pda_furthest_point_sampling(None, None, None, 2, 8, 0, None) == 0
