@@ -163,7 +163,7 @@ def pin_to_gpu_node(torch, device_index):
     """Keep this rank's threads on the CPUs of the NUMA node its GPU hangs off (what `numactl --cpunodebind` does for a launcher;
     the driver starts `python bench.py` bare).  A host-bound iteration is 10-15 % slower when the launching thread sits on the
     other socket, and the scheduler moves it between the two from run to run (KITTI, B = 4: 12.3-12.8 against 14.1-14.5 ms per
-    step, build/kitti_dist.py).  PDA_PIN_CPUS=0 leaves the affinity alone.  Returns a description for the result line."""
+    step, tools/experiments/kitti_dist.py).  PDA_PIN_CPUS=0 leaves the affinity alone.  Returns a description for the result line."""
     if os.environ.get("PDA_PIN_CPUS", "1") == "0":
         return "unchanged (PDA_PIN_CPUS=0)"
     global ALL_CPUS

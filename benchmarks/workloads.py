@@ -766,7 +766,7 @@ class DetectorTrainWorkload(TrainStepWorkload):
         # DETACHED: a caller that keeps the returned loss (`loss = wl.step()` in a loop) must not keep the iteration's autograd
         # graph alive with it.  With the graph of an earlier iteration alive, the capture of the tail graph on the next
         # iteration (graph_tail chosen by the probe above) dies inside hipStreamEndCapture (ROCm 7.2; torch/cuda/graphs.py
-        # capture_end; reproduced with build/soak4.py MODE=keep, gone with the reference dropped).
+        # capture_end; reproduced with tools/experiments/soak4.py MODE=keep, gone with the reference dropped).
         return ret['loss'].detach()
 
 
