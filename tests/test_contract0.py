@@ -50,7 +50,9 @@ def test_index_exact_cases_with_the_uncontracted_builds():
     env = dict(os.environ, PDA_LIB_PATH=lib, PDA_ORACLE_LIB="libpda_oracle_c0.so", PDA_EXPECT_CONTRACT="0")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         os.path.join(ROOT, "tests", "test_hip_parity.py"), os.path.join(ROOT, "tests", "test_ball_query_cells.py"),
-                        "-k", "fps or ball_query or three_nn or cells or config5"],
+                        # (the two largest cases -- config-5 sizes, 60 000 points: 17 s -- run in the contracted build only:
+                        # which expression the distance takes does not depend on the size)
+                        "-k", "(fps or ball_query or three_nn or cells) and not config5 and not shipped_once"],
                        env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     m = re.search(r"(\d+) passed", r.stdout)
