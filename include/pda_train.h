@@ -262,6 +262,27 @@ int pda_densitynet_bwd_unique(const float *x, const float *grad_y, const float *
                               float *grad_params, void *scratch, int64_t n, const int32_t *rowmap,
                               const float *row_weight, const int32_t *n_unique, int nsample, float eps,
                               pda_stream_t stream);
+/* Several independent DensityNet problems in ONE set of launches (the scales of a PDA layer: each of the nine passes is
+ * ~10 us of dependency latency on <= 128 workgroups, so two problems per launch cost what one does).  Per problem the
+ * arguments of the entries above; rowmap / row_weight / n_unique all NULL: every token (pda_densitynet_fwd), else the
+ * distinct slots (pda_densitynet_fwd_unique).  Forward reads x, params, writes y, stats, running (all six or none);
+ * backward reads x, grad_y, params, stats, writes grad_params.  scratch: pda_densitynet_scratch_bytes() each. */
+#define PDA_DENSITYNET_MAX_SCALES 4
+typedef struct pda_densitynet_scale {
+    const float *x, *grad_y, *params;
+    float *y, *stats;
+    void *scratch;
+    float *running[6]; /* mean1, var1, mean2, var2, mean3, var3 */
+    float *grad_params;
+    int64_t n;
+    const int32_t *rowmap;
+    const float *row_weight;
+    const int32_t *n_unique;
+    int nsample;
+    float eps, momentum;
+} pda_densitynet_scale_t;
+int pda_densitynet_fwd_multi(const pda_densitynet_scale_t *scales, int nscales, pda_stream_t stream);
+int pda_densitynet_bwd_multi(const pda_densitynet_scale_t *scales, int nscales, pda_stream_t stream);
 
 /* PDA grouper geometry (MI355X extension; pointnet2_utils.py:590-607, pointnet2_modules.py:905-913,:1000-1001),
  * point-major: xyz (B,N,3), new_xyz (B,M,3), idx (B,M,nsample) -> rppe (B,M,nsample,12) = [centre, neighbour,

@@ -11,6 +11,16 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PDA_LIB_PATH") or os.path.join(_HERE, "libpda_pointnet2.so")
 ABI_VERSION = 20
 
+
+class DensityNetScale(ctypes.Structure):
+    """pda_densitynet_scale_t (include/pda_train.h)."""
+    _fields_ = [("x", ctypes.c_void_p), ("grad_y", ctypes.c_void_p), ("params", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("stats", ctypes.c_void_p), ("scratch", ctypes.c_void_p), ("running", ctypes.c_void_p * 6),
+                ("grad_params", ctypes.c_void_p), ("n", ctypes.c_int64), ("rowmap", ctypes.c_void_p),
+                ("row_weight", ctypes.c_void_p), ("n_unique", ctypes.c_void_p), ("nsample", ctypes.c_int),
+                ("eps", ctypes.c_float), ("momentum", ctypes.c_float)]
+
+
 # Bumped by anything that writes parameters behind autograd's back (optimization.FlatAdamOneCycle.step updates the flat
 # parameter buffer through a raw pointer, so tensor version counters do not move): caches of derived tensors (bf16 weight
 # copies, BatchNorm folded into convolutions) key on it next to the version counters.
@@ -109,6 +119,8 @@ SIGNATURES = {
     "pda_densitynet_scratch_bytes": [],
     "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],
     "pda_densitynet_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _vp],
+    "pda_densitynet_fwd_multi": [_vp, _i, _vp],
+    "pda_densitynet_bwd_multi": [_vp, _i, _vp],
     "pda_densitynet_fwd_unique": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _i, _f, _f, _vp],
     "pda_densitynet_bwd_unique": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _i, _f, _vp],
     "pda_pda_geometry": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp],

@@ -151,7 +151,7 @@ __device__ __forceinline__ void dn_running(float* rm, float* rv, int c, double m
 
 // PASS: 1 = sum x, x^2; 2 = layer-2 statistics; 3 = layer-3 statistics; 4 = output
 template <int PASS>
-__global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __restrict__ x, const float* __restrict__ prm_g,
+__device__ __forceinline__ void densitynet_fwd_pass(const float* __restrict__ x, const float* __restrict__ prm_g,
                                                              float* __restrict__ stats, double* __restrict__ part_in,
                                                              double* __restrict__ part_out, float* __restrict__ y, int64_t n,
                                                              float eps, float momentum, float* rm1, float* rv1, float* rm2,
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < CNT; ++k) acc[k] = 0;
     const int64_t rows = dn_rows(R, n);
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)nblocks * 256) {
         const int64_t e = R.rowmap ? R.rowmap[t] : t;
         const float w = R.rowmap ? R.roww[t] : 1.f;
         const float xv = x[e];
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(256) void densitynet_fwd_kernel(const float* __rest
 //  B3 out: dW2[128] @0, db2[8] @128, s1[16] @136, s1x[16] @152 (sum dyh1 * x1h with x1h = normalised layer-1 input)
 //  B4 out: dW1[16] @0, db1[16] @16
 template <int PASS>
-__global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+__device__ __forceinline__ void densitynet_bwd_pass(const float* __restrict__ x, const float* __restrict__ dy,
                                                              const float* __restrict__ prm_g, const float* __restrict__ stats,
                                                              const double* __restrict__ p1, const double* __restrict__ p2,
                                                              const double* __restrict__ p3, double* __restrict__ part_out,
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
         __shared__ float stage[256][DN_H1 + DN_H2 + DN_H1 + 1];
         double mine = 0;
         const int k = threadIdx.x;
-        for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < rows; t0 += (int64_t)gridDim.x * 256) {
+        for (int64_t t0 = (int64_t)blockIdx.x * 256; t0 < rows; t0 += (int64_t)nblocks * 256) {
             const int64_t t = t0 + threadIdx.x;
             float* sp = stage[threadIdx.x];
             if (t < rows) {
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
     float acc[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) acc[k] = 0;
-    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)gridDim.x * 256) {
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < rows; t += (int64_t)nblocks * 256) {
         int64_t e;
         float w, gy;
         operands(t, e, w, gy);
@@ -398,7 +398,7 @@ __global__ __launch_bounds__(256) void densitynet_bwd_kernel(const float* __rest
 }
 
 // B5: all parameter gradients, in the layout of the parameter block
-__global__ __launch_bounds__(256) void densitynet_grads_kernel(const double* __restrict__ p1, const double* __restrict__ p2,
+__device__ __forceinline__ void densitynet_grads_pass(const double* __restrict__ p1, const double* __restrict__ p2,
                                                                const double* __restrict__ p3, const double* __restrict__ p4,
                                                                float* __restrict__ grads, int nblocks) {
     __shared__ double sums[DN_MAXP];
@@ -425,6 +425,47 @@ __global__ __launch_bounds__(256) void densitynet_grads_kernel(const double* __r
     }
 }
 
+// ---- launches: up to PDA_DENSITYNET_MAX_SCALES independent problems per launch (blockIdx.y) -------------------------------
+// The two scales of a PDA layer run the same nine passes on different tensors and parameters; each pass is ~10 us of
+// dependency latency on 64-128 workgroups, so two problems in one launch cost what one does.
+struct DnBatch {
+    pda_densitynet_scale_t s[PDA_DENSITYNET_MAX_SCALES];
+    int nblocks[PDA_DENSITYNET_MAX_SCALES];    // every problem keeps the grid it has on its own: same blocks, same sums, same bits
+};
+__device__ __forceinline__ DnRows dn_rows_of(const pda_densitynet_scale_t& S) {
+    return DnRows{S.rowmap, S.row_weight, S.n_unique, S.nsample};
+}
+__device__ __forceinline__ double* dn_part(const pda_densitynet_scale_t& S, int k) {
+    return (double*)S.scratch + (size_t)k * DN_BLOCKS * DN_MAXP;
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void densitynet_fwd_kernel(const DnBatch B) {
+    const pda_densitynet_scale_t& S = B.s[blockIdx.y];
+    const int nblocks = B.nblocks[blockIdx.y];
+    if ((int)blockIdx.x >= nblocks) return;
+    // partial buffers alternate: P1 -> a, P2 reads a writes b, P3 reads b writes a, P4 reads a
+    double* in = PASS == 1 ? nullptr : dn_part(S, PASS == 3 ? 1 : 0);
+    double* out = PASS == 4 ? nullptr : dn_part(S, PASS == 2 ? 1 : 0);
+    densitynet_fwd_pass<PASS>(S.x, S.params, S.stats, in, out, S.y, S.n, S.eps, S.momentum, S.running[0], S.running[1], S.running[2],
+                              S.running[3], S.running[4], S.running[5], nblocks, dn_rows_of(S));
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void densitynet_bwd_kernel(const DnBatch B) {
+    const pda_densitynet_scale_t& S = B.s[blockIdx.y];
+    const int nblocks = B.nblocks[blockIdx.y];
+    if ((int)blockIdx.x >= nblocks) return;
+    densitynet_bwd_pass<PASS>(S.x, S.grad_y, S.params, S.stats, dn_part(S, 0), dn_part(S, 1), dn_part(S, 2), dn_part(S, PASS - 1), S.n,
+                              S.eps, nblocks, dn_rows_of(S));
+}
+
+__global__ __launch_bounds__(256) void densitynet_grads_kernel(const DnBatch B) {
+    const pda_densitynet_scale_t& S = B.s[blockIdx.y];
+    const int nblocks = B.nblocks[blockIdx.y];
+    densitynet_grads_pass(dn_part(S, 0), dn_part(S, 1), dn_part(S, 2), dn_part(S, 3), S.grad_params, nblocks);
+}
+
 // Unique rows: the count is on the device (blocks behind it add zeros) and 5-10 x smaller than n; every pass opens with each
 // block adding up the previous pass's per-block partials, 16 loads per round.  Measured over the step's four scales (36
 // launches): 128 blocks 0.573 ms, 64 0.547, 32 0.690 (the staged outer-product pass of the backward wants the blocks), 16 1.07.
@@ -443,65 +484,75 @@ PDA_API int64_t pda_densitynet_scratch_bytes(void) {
 
 namespace pda {
 
-static int densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
-                          float* running_var1, float* running_mean2, float* running_var2, float* running_mean3, float* running_var3,
-                          int64_t n, float eps, float momentum, hipStream_t st, const DnRows& R, const char* what) {
-    PDA_REQUIRE(n >= 1, "%s: n = %lld", what, (long long)n);
-    PDA_REQUIRE(x && params && y && stats && scratch, "%s: null pointer", what);
-    const int grid = dn_grid(n, R);
-    double* pa = (double*)scratch;
-    double* pb = pa + (size_t)DN_BLOCKS * DN_MAXP;
-#define PDA_DN_FWD(P, IN, OUT) hipLaunchKernelGGL(densitynet_fwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, params, stats, IN, OUT, y, n, eps, \
-                                                  momentum, running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3, grid, R)
-    PDA_DN_FWD(1, (double*)nullptr, pa);
-    PDA_DN_FWD(2, pa, pb);
-    PDA_DN_FWD(3, pb, pa);
-    PDA_DN_FWD(4, pa, (double*)nullptr);
-#undef PDA_DN_FWD
+// one launch set for all scales: the grid's x extent is the largest problem's, a smaller one's spare blocks leave at once
+static int densitynet_launch(const pda_densitynet_scale_t* scales, int nscales, bool backward, hipStream_t st, const char* what) {
+    PDA_REQUIRE(scales && nscales >= 1 && nscales <= PDA_DENSITYNET_MAX_SCALES, "%s: 1..%d scales", what, PDA_DENSITYNET_MAX_SCALES);
+    DnBatch B{};
+    int grid = 1;
+    for (int i = 0; i < nscales; ++i) {
+        const pda_densitynet_scale_t& S = scales[i];
+        PDA_REQUIRE(S.n >= 1, "%s: n = %lld", what, (long long)S.n);
+        PDA_REQUIRE((S.rowmap == nullptr) == (S.row_weight == nullptr) && (S.rowmap == nullptr) == (S.n_unique == nullptr),
+                    "%s: rowmap, row_weight and n_unique come together", what);
+        PDA_REQUIRE(!S.rowmap || (S.nsample >= 1 && S.n % S.nsample == 0), "%s: n = %lld is not groups x nsample = %d", what,
+                    (long long)S.n, S.nsample);
+        PDA_REQUIRE(S.x && S.params && S.stats && S.scratch && (backward ? (S.grad_y && S.grad_params) : (S.y != nullptr)),
+                    "%s: null pointer", what);
+        bool any = false, all = true;
+        for (int k = 0; k < 6; ++k) { any = any || S.running[k]; all = all && S.running[k]; }
+        PDA_REQUIRE(backward || any == all, "%s: the six running statistics come together", what);
+        B.s[i] = S;
+        const int g = dn_grid(S.n, DnRows{S.rowmap, S.row_weight, S.n_unique, S.nsample});
+        B.nblocks[i] = g;
+        grid = g > grid ? g : grid;
+    }
+    const dim3 g3((unsigned)grid, (unsigned)nscales), b3(256);
+    if (!backward) {
+        hipLaunchKernelGGL(densitynet_fwd_kernel<1>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_fwd_kernel<2>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_fwd_kernel<3>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_fwd_kernel<4>, g3, b3, 0, st, B);
+    } else {
+        hipLaunchKernelGGL(densitynet_bwd_kernel<1>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_bwd_kernel<2>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_bwd_kernel<3>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_bwd_kernel<4>, g3, b3, 0, st, B);
+        hipLaunchKernelGGL(densitynet_grads_kernel, dim3(1, (unsigned)nscales), b3, 0, st, B);
+    }
     return check_launch(what);
 }
 
-static int densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
-                          void* scratch, int64_t n, float eps, hipStream_t st, const DnRows& R, const char* what) {
-    PDA_REQUIRE(n >= 1, "%s: n = %lld", what, (long long)n);
-    PDA_REQUIRE(x && grad_y && params && stats && grad_params && scratch, "%s: null pointer", what);
-    const int grid = dn_grid(n, R);
-    double* p1 = (double*)scratch;
-    double* p2 = p1 + (size_t)DN_BLOCKS * DN_MAXP;
-    double* p3 = p2 + (size_t)DN_BLOCKS * DN_MAXP;
-    double* p4 = p3 + (size_t)DN_BLOCKS * DN_MAXP;
-#define PDA_DN_BWD(P, OUT) hipLaunchKernelGGL(densitynet_bwd_kernel<P>, dim3(grid), dim3(256), 0, st, x, grad_y, params, stats, p1, p2, p3, OUT, n, eps, grid, R)
-    PDA_DN_BWD(1, p1);
-    PDA_DN_BWD(2, p2);
-    PDA_DN_BWD(3, p3);
-    PDA_DN_BWD(4, p4);
-#undef PDA_DN_BWD
-    hipLaunchKernelGGL(densitynet_grads_kernel, dim3(1), dim3(256), 0, st, p1, p2, p3, p4, grad_params, grid);
-    return check_launch(what);
-}
-
-static int dn_unique_rows(const int32_t* rowmap, const float* row_weight, const int32_t* n_unique, int64_t n, int nsample, DnRows& R,
-                          const char* what) {
-    PDA_REQUIRE(rowmap && row_weight && n_unique, "%s: null pointer", what);
-    PDA_REQUIRE(nsample >= 1 && n % nsample == 0, "%s: n = %lld is not groups x nsample = %d", what, (long long)n, nsample);
-    R = DnRows{rowmap, row_weight, n_unique, nsample};
-    return PDA_OK;
+static pda_densitynet_scale_t dn_one(const float* x, const float* grad_y, const float* params, float* y, float* stats, void* scratch,
+                                     float* grad_params, int64_t n, float eps, float momentum) {
+    pda_densitynet_scale_t S{};
+    S.x = x; S.grad_y = grad_y; S.params = params; S.y = y; S.stats = stats; S.scratch = scratch; S.grad_params = grad_params;
+    S.n = n; S.nsample = 1; S.eps = eps; S.momentum = momentum;
+    return S;
 }
 
 }  // namespace pda
 
+PDA_API int pda_densitynet_fwd_multi(const pda_densitynet_scale_t* scales, int nscales, pda_stream_t stream) {
+    return pda::densitynet_launch(scales, nscales, false, (hipStream_t)stream, "pda_densitynet_fwd_multi");
+}
+
+PDA_API int pda_densitynet_bwd_multi(const pda_densitynet_scale_t* scales, int nscales, pda_stream_t stream) {
+    return pda::densitynet_launch(scales, nscales, true, (hipStream_t)stream, "pda_densitynet_bwd_multi");
+}
+
 PDA_API int pda_densitynet_fwd(const float* x, const float* params, float* y, float* stats, void* scratch, float* running_mean1,
                                float* running_var1, float* running_mean2, float* running_var2, float* running_mean3,
                                float* running_var3, int64_t n, float eps, float momentum, pda_stream_t stream) {
-    return pda::densitynet_fwd(x, params, y, stats, scratch, running_mean1, running_var1, running_mean2, running_var2, running_mean3,
-                               running_var3, n, eps, momentum, (hipStream_t)stream, pda::DnRows{nullptr, nullptr, nullptr, 1},
-                               "pda_densitynet_fwd");
+    pda_densitynet_scale_t S = pda::dn_one(x, nullptr, params, y, stats, scratch, nullptr, n, eps, momentum);
+    float* r[6] = {running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3};
+    for (int k = 0; k < 6; ++k) S.running[k] = r[k];
+    return pda::densitynet_launch(&S, 1, false, (hipStream_t)stream, "pda_densitynet_fwd");
 }
 
 PDA_API int pda_densitynet_bwd(const float* x, const float* grad_y, const float* params, const float* stats, float* grad_params,
                                void* scratch, int64_t n, float eps, pda_stream_t stream) {
-    return pda::densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps, (hipStream_t)stream,
-                               pda::DnRows{nullptr, nullptr, nullptr, 1}, "pda_densitynet_bwd");
+    pda_densitynet_scale_t S = pda::dn_one(x, grad_y, params, nullptr, const_cast<float*>(stats), scratch, grad_params, n, eps, 0.f);
+    return pda::densitynet_launch(&S, 1, true, (hipStream_t)stream, "pda_densitynet_bwd");
 }
 
 PDA_API int pda_densitynet_fwd_unique(const float* x, const float* params, float* y, float* stats, void* scratch,
@@ -509,19 +560,21 @@ PDA_API int pda_densitynet_fwd_unique(const float* x, const float* params, float
                                       float* running_mean3, float* running_var3, int64_t n, const int32_t* rowmap,
                                       const float* row_weight, const int32_t* n_unique, int nsample, float eps, float momentum,
                                       pda_stream_t stream) {
-    pda::DnRows R;
-    if (int rc = pda::dn_unique_rows(rowmap, row_weight, n_unique, n, nsample, R, "pda_densitynet_fwd_unique")) return rc;
-    return pda::densitynet_fwd(x, params, y, stats, scratch, running_mean1, running_var1, running_mean2, running_var2, running_mean3,
-                               running_var3, n, eps, momentum, (hipStream_t)stream, R, "pda_densitynet_fwd_unique");
+    PDA_REQUIRE(rowmap && row_weight && n_unique, "pda_densitynet_fwd_unique: null pointer");
+    pda_densitynet_scale_t S = pda::dn_one(x, nullptr, params, y, stats, scratch, nullptr, n, eps, momentum);
+    float* r[6] = {running_mean1, running_var1, running_mean2, running_var2, running_mean3, running_var3};
+    for (int k = 0; k < 6; ++k) S.running[k] = r[k];
+    S.rowmap = rowmap; S.row_weight = row_weight; S.n_unique = n_unique; S.nsample = nsample;
+    return pda::densitynet_launch(&S, 1, false, (hipStream_t)stream, "pda_densitynet_fwd_unique");
 }
 
 PDA_API int pda_densitynet_bwd_unique(const float* x, const float* grad_y, const float* params, const float* stats,
                                       float* grad_params, void* scratch, int64_t n, const int32_t* rowmap, const float* row_weight,
                                       const int32_t* n_unique, int nsample, float eps, pda_stream_t stream) {
-    pda::DnRows R;
-    if (int rc = pda::dn_unique_rows(rowmap, row_weight, n_unique, n, nsample, R, "pda_densitynet_bwd_unique")) return rc;
-    return pda::densitynet_bwd(x, grad_y, params, stats, grad_params, scratch, n, eps, (hipStream_t)stream, R,
-                               "pda_densitynet_bwd_unique");
+    PDA_REQUIRE(rowmap && row_weight && n_unique, "pda_densitynet_bwd_unique: null pointer");
+    pda_densitynet_scale_t S = pda::dn_one(x, grad_y, params, nullptr, const_cast<float*>(stats), scratch, grad_params, n, eps, 0.f);
+    S.rowmap = rowmap; S.row_weight = row_weight; S.n_unique = n_unique; S.nsample = nsample;
+    return pda::densitynet_launch(&S, 1, true, (hipStream_t)stream, "pda_densitynet_bwd_unique");
 }
 
 // ---- PDA grouper geometry -------------------------------------------------------------------------------

@@ -579,6 +579,34 @@ def densitynet_bwd_unique(x, grad_y, params, stats, grad_params, scratch, n, row
     return 1
 
 
+def densitynet_multi(problems, backward=False):
+    """Several DensityNet problems in one set of launches (pda_densitynet_{fwd,bwd}_multi).  problems: dicts with x, params,
+    stats, scratch, n, eps, momentum and y + running (forward) or grad_y + grad_params (backward); optional unique rows:
+    rowmap, roww, off, groups, nsample (see densitynet_fwd_unique)."""
+    arr = (_lib.DensityNetScale * len(problems))()
+    for S, p in zip(arr, problems):
+        n = int(p["n"])
+        _numel_ok(p["x"], n, "x")
+        S.x = _chk(p["x"], "x", F32); S.params = _chk(p["params"], "params", F32); S.stats = _chk(p["stats"], "stats", F32)
+        S.scratch = _chk(p["scratch"], "scratch", torch.uint8)
+        S.n, S.nsample, S.eps, S.momentum = n, 1, float(p["eps"]), float(p.get("momentum") or 0.0)
+        if backward:
+            _numel_ok(p["grad_y"], n, "grad_y")
+            S.grad_y = _chk(p["grad_y"], "grad_y", F32); S.grad_params = _chk(p["grad_params"], "grad_params", F32)
+        else:
+            _numel_ok(p["y"], n, "y")
+            S.y = _chk(p["y"], "y", F32)
+            if p.get("running") is not None:
+                _buffers_written(p["running"])
+                for k, t in enumerate(p["running"]):
+                    S.running[k] = _chk(t, "running", F32)
+        if p.get("rowmap") is not None:
+            S.rowmap, S.row_weight, S.n_unique = _unique_rows(p["rowmap"], p["roww"], p["off"], p["groups"], n, p["nsample"])
+            S.nsample = int(p["nsample"])
+    _call("pda_densitynet_bwd_multi" if backward else "pda_densitynet_fwd_multi", problems[0]["x"], ctypes.addressof(arr), len(problems))
+    return 1
+
+
 def pda_geometry(xyz, new_xyz, idx, rppe, dscale, b, n, m, nsample, radius):
     """MI355X extension: relative-position input and normalised gaussian density of a PDA scale (csrc/densitynet.hip)."""
     _numel_ok(xyz, b * n * 3, "xyz"); _numel_ok(new_xyz, b * m * 3, "new_xyz"); _numel_ok(idx, b * m * nsample, "idx")

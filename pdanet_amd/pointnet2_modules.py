@@ -721,7 +721,7 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
         feats_pm = features.transpose(1, 2).contiguous()                      # (B, N, C)
         global_in = torch.cat([new_xyz, new_xyz_feature], dim=-1)             # (B, M, 3 + C)   (:856)
         centre = new_xyz.unsqueeze(2)                                         # (B, M, 1, 3)
-        pre = []
+        pre, geo = [], []
         for i in range(len(self.groupers)):
             r, ns = self.groupers[i].radius, self.nsamples[i]
             fused_geo = (FUSED_GEOMETRY and xyz.is_cuda and xyz.dtype == torch.float32 and ns <= 64 and ns & (ns - 1) == 0
@@ -743,14 +743,21 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 dscale = density / density.max(dim=2, keepdim=True)[0]
                 # relative position encoding [centre, nbr, centre - nbr, direction] (:907-913)
                 rppe = torch.cat([centre.expand(B, npoint, ns, 3), nbr, -diff, direction], dim=-1)
-            dn = self.point_density[i].densitynet
-            if pointnet2_utils.DensityNetFused.supported(dscale, dn):
-                # 4 + 5 launches instead of ~45; with a plan on the device (its token count not read yet), over the
-                # distinct slots only -- dscale of a repeat slot equals its group's slot 0 (the same neighbour)
-                part = plan_parts[i] if (plan_parts is not None and fused_geo) else None
-                dscale = pointnet2_utils.densitynet(dn, dscale, part)
-            else:
-                for conv, bn in zip(dn.mlp_convs, dn.mlp_bns):
+            geo.append((rppe, dscale, fused_geo))
+        # DensityNet of every scale: the scales that take the fused passes share ONE set of launches
+        dns = [self.point_density[i].densitynet for i in range(len(self.groupers))]
+        fused = [i for i in range(len(self.groupers)) if pointnet2_utils.DensityNetFused.supported(geo[i][1], dns[i])]
+        dsc = [g[1] for g in geo]
+        if fused:
+            # 4 + 5 launches instead of ~45; with a plan on the device (its token count not read yet), over the distinct
+            # slots only -- dscale of a repeat slot equals its group's slot 0 (the same neighbour)
+            parts_f = [plan_parts[i] if (plan_parts is not None and geo[i][2]) else None for i in fused]
+            for i, y in zip(fused, pointnet2_utils.densitynet_multi([dns[i] for i in fused], [dsc[i] for i in fused], parts_f)):
+                dsc[i] = y
+        for i in range(len(self.groupers)):
+            rppe, dscale = geo[i][0], dsc[i]
+            if i not in fused:
+                for conv, bn in zip(dns[i].mlp_convs, dns[i].mlp_bns):
                     if _can_fold(conv, bn):
                         dscale = _linear_relu(dscale, *_folded_conv_bn(conv, bn))
                     else:

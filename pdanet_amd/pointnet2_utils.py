@@ -449,7 +449,64 @@ class DensityNetFused(Function):
         return (None, None, None, None, None) + tuple(g.view(s) for g, s in zip(pieces, ctx.shapes))
 
 
+class DensityNetFusedMulti(Function):
+    """DensityNetFused for the k scales of a PDA layer in ONE set of launches (pda_densitynet_{fwd,bwd}_multi): each of the
+    nine passes is ~10 us of dependency latency on <= 128 workgroups, so k problems per launch cost what one does.  Per scale
+    the same arithmetic as DensityNetFused (bit for bit).  apply(metas, *xs, *params): metas = [(eps, momentum, running,
+    part)] per scale, 12 parameter tensors per scale; returns the k outputs."""
+
+    @staticmethod
+    def forward(ctx, metas, *flat):
+        k = len(metas)
+        xs, params = [x.contiguous() for x in flat[:k]], flat[k:]
+        nparam, nscratch = pointnet2.densitynet_sizes()
+        problems, saved, ys = [], [], []
+        for i, (x, (eps, momentum, running, part)) in enumerate(zip(xs, metas)):
+            packed = torch.cat([p.reshape(-1) for p in params[12 * i:12 * i + 12]])
+            assert packed.numel() == nparam
+            y = torch.empty_like(x)
+            stats = torch.empty((46,), dtype=torch.float32, device=x.device)
+            scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
+            prob = dict(x=x, params=packed, y=y, stats=stats, scratch=scratch, running=running, n=x.numel(), eps=eps, momentum=momentum)
+            keep = [x, packed, stats]
+            if part is not None:
+                _, off, rowmap, roww, G, ns = part
+                prob.update(rowmap=rowmap, roww=roww, off=off, groups=G, nsample=ns)
+                keep += [off, rowmap, roww]
+            problems.append(prob)
+            saved.append((keep, None if part is None else (part[4], part[5]), eps))
+            ys.append(y)
+        pointnet2.densitynet_multi(problems)
+        ctx.save_for_backward(*[t for keep, _, _ in saved for t in keep])
+        ctx.layout = [(len(keep), uq, eps) for keep, uq, eps in saved]
+        ctx.shapes = [p.shape for p in params]
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *grad_ys):
+        nparam, nscratch = pointnet2.densitynet_sizes()
+        tensors = list(ctx.saved_tensors)
+        problems, grads = [], []
+        for (cnt, uq, eps), gy in zip(ctx.layout, grad_ys):
+            keep, tensors = tensors[:cnt], tensors[cnt:]
+            x, packed, stats = keep[:3]
+            g = torch.empty((nparam,), dtype=torch.float32, device=x.device)
+            scratch = torch.empty((nscratch,), dtype=torch.uint8, device=x.device)
+            gy = torch.zeros_like(x) if gy is None else gy.contiguous()
+            prob = dict(x=x, grad_y=gy, params=packed, stats=stats, grad_params=g, scratch=scratch, n=x.numel(), eps=eps)
+            if uq is not None:
+                prob.update(off=keep[3], rowmap=keep[4], roww=keep[5], groups=uq[0], nsample=uq[1])
+            problems.append(prob)
+            grads.append(g)
+        pointnet2.densitynet_multi(problems, backward=True)
+        out = []
+        for i, g in enumerate(grads):
+            out += [t.view(s) for t, s in zip(torch.split(g, DensityNetFused.SPLITS), ctx.shapes[12 * i:12 * i + 12])]
+        return (None,) + (None,) * len(grads) + tuple(out)
+
+
 FUSED_DENSITYNET = True
+DENSITYNET_MULTI = os.environ.get("PDA_DENSITYNET_MULTI", "1") != "0"       # the scales of a layer share their launches
 DENSITYNET_UNIQUE = os.environ.get("PDA_DENSITYNET_UNIQUE", "1") != "0"     # distinct slots only where a plan exists
 
 
@@ -465,6 +522,25 @@ def densitynet(dn, x, part=None):
     for c, b in zip(convs, bns):
         params += [c.weight, c.bias, b.weight, b.bias]
     return DensityNetFused.apply(x, bns[0].eps, bns[0].momentum, running, part if DENSITYNET_UNIQUE else None, *params)
+
+
+def densitynet_multi(dns, xs, parts):
+    """The DensityNets `dns` of the scales of one layer on their inputs `xs` (parts: the scales' plan parts or None each): one
+    set of launches for all of them."""
+    if not DENSITYNET_MULTI or len(dns) == 1 or len(dns) > 4:
+        return [densitynet(dn, x, part) for dn, x, part in zip(dns, xs, parts)]
+    metas, params = [], []
+    for dn, part in zip(dns, parts):
+        convs, bns = dn.mlp_convs, dn.mlp_bns
+        running = None
+        if all(b.track_running_stats for b in bns):
+            running = [t for b in bns for t in (b.running_mean, b.running_var)]
+            for b in bns:
+                bump_bn_counter(b)
+        metas.append((bns[0].eps, bns[0].momentum, running, part if DENSITYNET_UNIQUE else None))
+        for c, b in zip(convs, bns):
+            params += [c.weight, c.bias, b.weight, b.bias]
+    return list(DensityNetFusedMulti.apply(metas, *xs, *params))
 
 
 class LinearLongTokens(Function):

@@ -90,6 +90,48 @@ def test_densitynet_on_distinct_slots_equals_dense(G, ns, p_single, p_full, spar
         assert torch.allclose(b1.running_var, b2.running_var, atol=1e-6, rtol=1e-5)
 
 
+def test_scales_sharing_their_launches_equal_one_scale_at_a_time():
+    """pda_densitynet_{fwd,bwd}_multi (the scales of a layer as blockIdx.y of one set of launches) against one call per scale:
+    three problems of different sizes -- distinct slots, every token, distinct slots -- give the same y, running statistics and
+    parameter gradients bit for bit (per problem the same blocks add the same numbers in the same order)."""
+    import numpy as np
+    from pdanet_amd import pointnet2_modules as pm, pointnet2_utils as pu
+    from test_ragged_tokens import padded_idx
+    rng = np.random.default_rng(5)
+    shapes = [(3000, 16), (700, 32), (9000, 8)]
+    xs, parts = [], []
+    val = torch.rand(6000, device="cuda")
+    for k, (G, ns) in enumerate(shapes):
+        idx, _ = padded_idx(G, ns, 6000, rng)
+        idx_t = torch.from_numpy(idx).cuda().view(1, G, ns)
+        xs.append(val[idx_t.long()].view(1, G, ns, 1).contiguous())
+        parts.append(None if k == 1 else pu.ragged_plan_parts([idx_t])[0][0])
+
+    def models():
+        out = []
+        for k in range(3):
+            torch.manual_seed(10 + k)
+            dn = pm.DensityNet().cuda().train()
+            with torch.no_grad():
+                for b in dn.mlp_bns:
+                    b.weight.uniform_(0.5, 1.5); b.bias.normal_(0, 0.3); b.running_mean.normal_(); b.running_var.uniform_(0.5, 2)
+            out.append(dn)
+        return out
+    gos = [torch.randn_like(x) for x in xs]
+    res = {}
+    try:
+        for multi in (True, False):
+            pu.DENSITYNET_MULTI = multi
+            dns = models()
+            ys = pu.densitynet_multi(dns, xs, parts)
+            grads = torch.autograd.grad(ys, [p for dn in dns for p in dn.parameters()], gos)
+            res[multi] = (ys, grads, [t.clone() for dn in dns for b in dn.mlp_bns for t in (b.running_mean, b.running_var, b.num_batches_tracked)])
+    finally:
+        pu.DENSITYNET_MULTI = True
+    for a, b in zip(res[True][0] + list(res[True][1]) + res[True][2], res[False][0] + list(res[False][1]) + res[False][2]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("B,N,M,ns,r", [(1, 50, 7, 16, 0.8), (2, 4096, 1000, 32, 1.6), (3, 300, 129, 8, 4.8)])
 def test_pda_geometry_kernel_matches_torch_expression(B, N, M, ns, r):
     from pdanet_amd import pointnet2_batch_cuda as ext, pointnet2_utils as pu
