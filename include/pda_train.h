@@ -284,6 +284,12 @@ typedef struct pda_densitynet_scale {
 int pda_densitynet_fwd_multi(const pda_densitynet_scale_t *scales, int nscales, pda_stream_t stream);
 int pda_densitynet_bwd_multi(const pda_densitynet_scale_t *scales, int nscales, pda_stream_t stream);
 
+/* Inference: the three layers with their BatchNorms folded in (running statistics), one launch, one thread per token.
+ * folded (pda_densitynet_eval_param_count() = 177 floats): w1[16] b1[16] W2[8][16] b2[8] w3[8] b3 with
+ * W' = W * gamma / sqrt(running_var + eps), b' = (bias - running_mean) * gamma / sqrt(running_var + eps) + beta. */
+int pda_densitynet_eval_param_count(void);
+int pda_densitynet_eval(const float *x, const float *folded, float *y, int64_t n, pda_stream_t stream);
+
 /* PDA grouper geometry (MI355X extension; pointnet2_utils.py:590-607, pointnet2_modules.py:905-913,:1000-1001),
  * point-major: xyz (B,N,3), new_xyz (B,M,3), idx (B,M,nsample) -> rppe (B,M,nsample,12) = [centre, neighbour,
  * centre - neighbour, (neighbour - centre) / radius] and dscale (B,M,nsample) = gaussian density

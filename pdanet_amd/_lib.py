@@ -116,9 +116,11 @@ SIGNATURES = {
     "pda_group_attention_ragged_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_group_attention_ragged_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, ctypes.c_int64, _i, _i, _i, _vp],
     "pda_densitynet_param_count": [],
+    "pda_densitynet_eval_param_count": [],
     "pda_densitynet_scratch_bytes": [],
     "pda_densitynet_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _f, _vp],
     "pda_densitynet_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _f, _vp],
+    "pda_densitynet_eval": [_vp, _vp, _vp, ctypes.c_int64, _vp],
     "pda_densitynet_fwd_multi": [_vp, _i, _vp],
     "pda_densitynet_bwd_multi": [_vp, _i, _vp],
     "pda_densitynet_fwd_unique": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_int64, _vp, _vp, _vp, _i, _f, _f, _vp],

@@ -577,6 +577,47 @@ PDA_API int pda_densitynet_bwd_unique(const float* x, const float* grad_y, const
     return pda::densitynet_launch(&S, 1, true, (hipStream_t)stream, "pda_densitynet_bwd_unique");
 }
 
+// ---- inference: BatchNorm folded into the convolutions (running statistics), the three layers in one launch -------------
+// folded: w1[16] b1[16] W2[8][16] b2[8] w3[8] b3 (pointnet2_modules._folded_conv_bn per layer)
+namespace pda {
+constexpr int DN_EVAL_NPARAM = 2 * DN_H1 + DN_H2 * DN_H1 + DN_H2 + DN_H2 + 1;
+
+__global__ __launch_bounds__(256) void densitynet_eval_kernel(const float* __restrict__ x, const float* __restrict__ folded,
+                                                              float* __restrict__ y, int64_t n) {
+    __shared__ float prm[DN_EVAL_NPARAM];
+    for (int k = threadIdx.x; k < DN_EVAL_NPARAM; k += 256) prm[k] = folded[k];
+    __syncthreads();
+    const float *w1 = prm, *b1 = prm + DN_H1, *W2 = prm + 2 * DN_H1, *b2 = W2 + DN_H2 * DN_H1, *w3 = b2 + DN_H2;
+    const float b3 = w3[DN_H2];
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (int64_t)gridDim.x * 256) {
+        const float xv = x[t];
+        float h1[DN_H1];
+#pragma unroll
+        for (int c = 0; c < DN_H1; ++c) h1[c] = fmaxf(w1[c] * xv + b1[c], 0.f);
+        float z3 = b3;
+#pragma unroll
+        for (int j = 0; j < DN_H2; ++j) {
+            float a = b2[j];
+#pragma unroll
+            for (int c = 0; c < DN_H1; ++c) a += W2[j * DN_H1 + c] * h1[c];
+            z3 += w3[j] * fmaxf(a, 0.f);
+        }
+        y[t] = fmaxf(z3, 0.f);
+    }
+}
+}  // namespace pda
+
+PDA_API int pda_densitynet_eval_param_count(void) { return pda::DN_EVAL_NPARAM; }
+
+PDA_API int pda_densitynet_eval(const float* x, const float* folded, float* y, int64_t n, pda_stream_t stream) {
+    PDA_REQUIRE(n >= 0, "pda_densitynet_eval: n = %lld", (long long)n);
+    if (n == 0) return PDA_OK;
+    PDA_REQUIRE(x && folded && y, "pda_densitynet_eval: null pointer");
+    const int64_t b = pda::divup64(n, 256);
+    hipLaunchKernelGGL(pda::densitynet_eval_kernel, dim3((unsigned)(b < 2048 ? b : 2048)), dim3(256), 0, (hipStream_t)stream, x, folded, y, n);
+    return pda::check_launch("pda_densitynet_eval");
+}
+
 // ---- PDA grouper geometry -------------------------------------------------------------------------------
 // QueryAndGroup_alone_grouped_density_directional (pointnet2_utils.py:590-607) + the relative-position
 // assembly of the PDA layer (pointnet2_modules.py:905-913) + PointConvDensitySetAbstraction's per-group max

@@ -534,6 +534,14 @@ def densitynet_sizes():
     return int(lib.pda_densitynet_param_count()), int(lib.pda_densitynet_scratch_bytes())
 
 
+def densitynet_eval(x, folded, y, n):
+    """MI355X extension: inference DensityNet, BatchNorm folded into the three layers, one launch (csrc/densitynet.hip).
+    folded: 177 floats w1[16] b1[16] W2[8][16] b2[8] w3[8] b3."""
+    _numel_ok(x, n, "x"); _numel_ok(y, n, "y"); _numel_ok(folded, int(_lib.load().pda_densitynet_eval_param_count()), "folded")
+    _call("pda_densitynet_eval", x, _chk(x, "x", F32), _chk(folded, "folded", F32), _chk(y, "y", F32), n)
+    return 1
+
+
 def densitynet_fwd(x, params, y, stats, scratch, running, n, eps, momentum):
     """MI355X extension: training-mode DensityNet on a scalar input per token (csrc/densitynet.hip).
     running: [rm1, rv1, rm2, rv2, rm3, rv3] or None."""

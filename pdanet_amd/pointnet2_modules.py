@@ -195,6 +195,35 @@ def _mlp_lastdim(layers, x, pool=False, mfma=False):
     return x
 
 
+FUSED_DENSITYNET_EVAL = os.environ.get("PDA_DENSITYNET_EVAL", "1") != "0"
+
+
+def _densitynet_eval_ok(dn, x):
+    convs, bns = list(dn.mlp_convs), list(dn.mlp_bns)
+    return (FUSED_DENSITYNET_EVAL and x.is_cuda and x.dtype == torch.float32 and x.shape[-1] == 1 and not torch.is_grad_enabled()
+            and len(convs) == 3 and [c.out_channels for c in convs] == [16, 8, 1] and convs[0].in_channels == 1
+            and all(_can_fold(c, b) for c, b in zip(convs, bns)) and not torch.is_autocast_enabled())
+
+
+def _densitynet_eval(dn, x):
+    """DensityNet (pointnet2_modules.py:958-981) in inference on x (..., 1): relu(W3' relu(W2' relu(w1' x + b1') + b2') + b3') with
+    the BatchNorms folded in (_folded_conv_bn), one kernel instead of three tiny GEMMs with bias + ReLU epilogues.  The packed
+    parameter block is cached on the module, keyed on the folded tensors (which are themselves re-made when a weight, a BatchNorm
+    parameter or a running statistic changes)."""
+    folded = [_folded_conv_bn(c, b) for c, b in zip(dn.mlp_convs, dn.mlp_bns)]
+    key = tuple((t.data_ptr(), t._version) for wb in folded for t in wb)
+    cache = dn.__dict__.get("_pda_eval_block")
+    if cache is None or cache[0] != key:
+        with torch.no_grad():
+            block = torch.cat([t.reshape(-1).float() for wb in folded for t in wb]).contiguous()
+        cache = (key, block, folded)       # `folded` kept alive: its addresses are the key
+        dn.__dict__["_pda_eval_block"] = cache
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    pointnet2_utils.pointnet2.densitynet_eval(x, cache[1], y, x.numel())
+    return y
+
+
 def _transformer_batch_first(tr, x, pool=False):
     """TransformerEncoderLayerPreNorm.forward (PointFormer.py:28-38) on x (batch, seq, D) instead of
     (seq, batch, D), with the module's own parameters; dropout is 0 in PDA-SSD (:632).  pool=True also takes
@@ -756,7 +785,9 @@ class PointnetSAModuleMSG_WithSampling_Ellipsoid(_SAModuleBase):
                 dsc[i] = y
         for i in range(len(self.groupers)):
             rppe, dscale = geo[i][0], dsc[i]
-            if i not in fused:
+            if i not in fused and _densitynet_eval_ok(dns[i], dscale):
+                dscale = _densitynet_eval(dns[i], dscale)          # inference: the three folded layers in one launch
+            elif i not in fused:
                 for conv, bn in zip(dns[i].mlp_convs, dns[i].mlp_bns):
                     if _can_fold(conv, bn):
                         dscale = _linear_relu(dscale, *_folded_conv_bn(conv, bn))

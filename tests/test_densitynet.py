@@ -90,6 +90,30 @@ def test_densitynet_on_distinct_slots_equals_dense(G, ns, p_single, p_full, spar
         assert torch.allclose(b1.running_var, b2.running_var, atol=1e-6, rtol=1e-5)
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 5, 1), (2, 4096, 32, 1), (3, 1111, 8, 1)])
+def test_inference_kernel_matches_module_in_eval_mode(shape):
+    """pda_densitynet_eval (BatchNorm folded into the three layers, one launch) against the torch module in eval mode (float64),
+    and the cached parameter block follows a change of the running statistics."""
+    from pdanet_amd import pointnet2_modules as pm
+    torch.manual_seed(sum(shape))
+    dn = pm.DensityNet().cuda().eval()
+    with torch.no_grad():
+        for b in dn.mlp_bns:
+            b.weight.uniform_(0.5, 1.5); b.bias.normal_(0, 0.3); b.running_mean.normal_(0, 0.2); b.running_var.uniform_(0.5, 2)
+    x = torch.rand(shape, device="cuda")
+    for _ in range(2):
+        ref = pm.DensityNet().cuda().double().eval()
+        ref.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in dn.state_dict().items()})
+        with torch.no_grad():
+            assert pm._densitynet_eval_ok(dn, x)
+            y = pm._densitynet_eval(dn, x)
+            yr = ref(x.double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+        assert y.shape == x.shape and (y.double() - yr).abs().max().item() < 1e-5
+        with torch.no_grad():                      # second round: other statistics, the cached block must not survive them
+            dn.mlp_bns[1].running_mean.add_(0.5)
+            dn.mlp_bns[2].running_var.mul_(1.7)
+
+
 def test_scales_sharing_their_launches_equal_one_scale_at_a_time():
     """pda_densitynet_{fwd,bwd}_multi (the scales of a layer as blockIdx.y of one set of launches) against one call per scale:
     three problems of different sizes -- distinct slots, every token, distinct slots -- give the same y, running statistics and
